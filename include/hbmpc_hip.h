@@ -1,0 +1,219 @@
+/*
+ * hbmpc_hip.h -- C ABI of the MI355X (gfx950) Shamir share-arithmetic engine for HoneyBadgerMPC.
+ *
+ * This is the drop-in boundary for ONE path of Stoffel-Labs/mpc-protocols: the field arithmetic
+ * behind RobustShare<F> / SecretSharingScheme<F> (F = ark_bls12_381::Fr) that the async protocol
+ * code calls inline.  Each entry point names the reference interface it replaces (paths relative
+ * to the reference's mpc/src/).  The Rust shim that binds these symbols is in INTEGRATION.md.
+ *
+ * Conventions (they follow the reference's own exported C ABI, ffi/c_bindings/mod.rs:17-35 and
+ * ffi/c_bindings/share/mod.rs:18-37, so both ABIs look alike):
+ *   - U256 = canonical integer < r, four u64 limbs, least-significant limb first
+ *     (Fr <-> U256 exactly as ffi/c_bindings/mod.rs:37-49: into_bigint().0 / from_bigint).
+ *     Inputs MUST be canonical (< r); the reference panics on a non-canonical U256
+ *     (from_bigint(..).unwrap()), this library leaves the result unspecified.
+ *   - every call returns a ShareErrorCode; it is the only error channel
+ *     (hbmpc_last_error gives a message for the calling thread's last failure on that ctx).
+ *   - the CALLER allocates every output buffer (no allocator is shared across the boundary).
+ *   - there is no CPU path: every entry point needs a HIP device and fails with
+ *     HBMPC_NO_DEVICE when there is none.
+ *   - thread-safe and re-entrant: calls on one ctx from several threads serialise on the ctx's
+ *     stream; use one ctx per thread (or the hbmpc_dev_* calls with your own streams) to overlap.
+ *
+ * Array layouts (B secrets / G chunks are the batch dimension):
+ *   "chunk-major"  X[G][m]  : the m = degree+1 coefficients/secrets of one chunk are contiguous
+ *                             (how the reference holds them: shares.chunks_exact(degree+1),
+ *                             batch_recon.rs:160; Vec<Vec<F>> results, robust_interpolate.rs:401)
+ *   "party-major"  Y[n][G]  : one party's (sender's / recipient's) values for all chunks are
+ *                             contiguous (y_shares_by_recipient[recipient][chunk],
+ *                             batch_recon.rs:158-165; evals_by_sender[i].1[c],
+ *                             robust_interpolate.rs:285)
+ *
+ * Two API levels:
+ *   hbmpc_*      host pointers, synchronous (H2D, kernels, D2H inside the call)
+ *   hbmpc_dev_*  device pointers + a hipStream_t (as void*), asynchronous: for pipelines that keep
+ *                shares resident in HBM between protocol steps (and for the benchmark).
+ */
+#ifndef HBMPC_HIP_H
+#define HBMPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ffi/c_bindings/mod.rs:17-21 */
+typedef struct {
+    uint64_t data[4];
+} U256;
+
+/* ffi/c_bindings/share/mod.rs:18-37 (same order, same values); the HBMPC_* values are new and
+ * never produced by the reference: they report conditions the Rust code cannot have. */
+typedef enum {
+    ShareSuccess = 0,
+    InsufficientShares = 1,
+    DegreeMismatch = 2,
+    IdMismatch = 3,
+    InvalidInput = 4,
+    TypeMismatch = 5,
+    NoSuitableDomain = 6,
+    PolynomialOperationError = 7,
+    DecodingError = 8,
+    HBMPC_NO_DEVICE = 100,    /* no HIP device / HIP runtime error (see hbmpc_last_error) */
+    HBMPC_OUT_OF_MEMORY = 101 /* device allocation failed */
+} ShareErrorCode;
+
+/* ffi/c_bindings/share/mod.rs:50-53 (FieldKind) */
+typedef enum { Bls12_381Fr = 0 } FieldKind;
+
+/* per-chunk status written by the batch-recover calls */
+enum {
+    HBMPC_CHUNK_OPTIMISTIC = 0, /* all degree+t+1 lowest senders agreed (robust_interpolate.rs:417) */
+    HBMPC_CHUNK_FALLBACK = 1    /* recovered by the OEC/Gao path (robust_interpolate.rs:433-438) */
+    /* any other value: the ShareErrorCode recover_secret returned for that chunk */
+};
+
+typedef struct hbmpc_ctx hbmpc_ctx;
+
+/* summary of one batch-recover call (device API writes it to device memory) */
+typedef struct {
+    uint32_t n_fallback;   /* chunks that took the OEC/Gao path                         */
+    uint32_t n_failed;     /* chunks whose fallback failed                               */
+    uint32_t first_failed; /* lowest failing chunk index (valid when n_failed > 0)       */
+    uint32_t first_error;  /* its ShareErrorCode: what the reference's `?` would return  */
+} hbmpc_recover_summary;
+
+/* ---- context --------------------------------------------------------------------------- */
+/* device: HIP device ordinal (>= 0).  There is no CPU mode. */
+ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out);
+void hbmpc_destroy(hbmpc_ctx* ctx);
+const char* hbmpc_last_error(const hbmpc_ctx* ctx);
+const char* hbmpc_version(void);
+
+/* ---- device memory / stream helpers (for hosts without their own HIP binding) ------------ */
+ShareErrorCode hbmpc_dev_alloc(hbmpc_ctx* ctx, size_t bytes, void** dptr_out);
+ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr);
+ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
+ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream); /* stream == NULL: the ctx's own stream */
+
+/* ==== a3: RobustShare::compute_shares / NonRobustShare::compute_shares ======================
+ * replaces honeybadger/robust_interpolate/robust_interpolate.rs:52-82 and
+ * common/share/shamir.rs:158-196 for B secrets at once.
+ * coeffs[B][d+1] chunk-major: coeffs[b][0] = secret, coeffs[b][1..=d] = the rng draws of
+ * DensePolynomial::rand (the host draws them so results stay bit-exact with its rng).
+ * shares_out[n][B] party-major: shares_out[j][b] = share with id j of secret b.
+ * Errors: InvalidInput if n <= d (:59-64); NoSuitableDomain if next_pow2(n) > 2^32. */
+ShareErrorCode hbmpc_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B, size_t n, size_t d,
+                                    U256* shares_out);
+ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs_dev, size_t B, size_t n, size_t d,
+                                        U256* shares_out_dev, void* stream);
+
+/* ==== a4+a5: make_vandermonde + apply_vandermonde ===========================================
+ * replaces common/share/mod.rs:31-76 as used by BatchReconNode::init_batch_reconstruct[_many]
+ * (batch_recon.rs:114-115,157-165), RanSha (share_gen.rs:415-419) and RanDouSha
+ * (ran_dou_sha/mod.rs:392-403).
+ * x[G][d+1] chunk-major -> y_out[n][G] party-major, y_out[j][g] = sum_k alpha_j^k x[g][k]. */
+ShareErrorCode hbmpc_vandermonde_apply(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d, U256* y_out);
+ShareErrorCode hbmpc_dev_vandermonde_apply(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
+                                           U256* y_out_dev, void* stream);
+/* make_vandermonde alone (common/share/mod.rs:31-45): v_out[n][d+1], host memory. */
+ShareErrorCode hbmpc_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, U256* v_out);
+
+/* ==== a7: batch_recover_secret ==============================================================
+ * replaces robust_interpolate.rs:284-443.  sender_ids[S] in ARRIVAL order (sorted inside, :313),
+ * evals[S][G] party-major in the same order as sender_ids.
+ * coeffs_out[G][d+1] chunk-major, zero-padded to d+1 coefficients.
+ * ncoeffs_out[G] (nullable): the length of the Vec<F> the reference returns for that chunk:
+ *   d+1 on the optimistic path (:419), the trimmed length on the fallback path (:437-438).
+ * status_out[G] (nullable): HBMPC_CHUNK_* per chunk.
+ * Return value: what the reference returns -- the validation errors of :290-341, or the error of
+ * the lowest-index chunk whose fallback fails (:437 `?`); outputs of other chunks are still written.
+ * P(0)-only variant (the EvalBatch arm keeps coeffs[0] only, batch_recon.rs:384-391):
+ * secrets_out[G]. */
+ShareErrorCode hbmpc_batch_recover(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals, size_t G,
+                                   size_t n, size_t d, size_t t, U256* coeffs_out, uint32_t* ncoeffs_out,
+                                   uint8_t* status_out);
+ShareErrorCode hbmpc_batch_recover_p0(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals,
+                                      size_t G, size_t n, size_t d, size_t t, U256* secrets_out,
+                                      uint8_t* status_out);
+/* device variants: sender_ids is a HOST array (it selects the constant tables); every other
+ * pointer is device memory; summary_dev (nullable) receives an hbmpc_recover_summary.  The return
+ * value covers validation only; read summary_dev after the stream has drained for chunk errors. */
+ShareErrorCode hbmpc_dev_batch_recover(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals_dev,
+                                       size_t G, size_t n, size_t d, size_t t, U256* coeffs_out_dev,
+                                       uint32_t* ncoeffs_out_dev, uint8_t* status_out_dev,
+                                       hbmpc_recover_summary* summary_dev, void* stream);
+ShareErrorCode hbmpc_dev_batch_recover_p0(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals_dev,
+                                          size_t G, size_t n, size_t d, size_t t, U256* secrets_out_dev,
+                                          uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev,
+                                          void* stream);
+
+/* ==== a6: RobustShare::recover_secret (one polynomial) ======================================
+ * replaces robust_interpolate.rs:94-157 (+ robust_interpolate_fnt :206-266, oec_decode :579-628,
+ * gao_rs_decode :456-538).  ids[S]/vals[S]/degrees[S] in any order.
+ * coeffs_out has room for d+1 = degrees[0]+1 elements; *ncoeffs_out = trimmed length
+ * (DensePolynomial normal form); *secret_out = P(0). */
+ShareErrorCode hbmpc_recover_secret(hbmpc_ctx* ctx, const size_t* ids, const size_t* degrees, const U256* vals,
+                                    size_t S, size_t n, size_t t, U256* coeffs_out, size_t* ncoeffs_out,
+                                    U256* secret_out);
+/* gao_rs_decode alone (robust_interpolate.rs:456-538): received[n], erasure positions,
+ * k = message length; coeffs_out has room for k elements. */
+ShareErrorCode hbmpc_gao_rs_decode(hbmpc_ctx* ctx, const U256* received, size_t k, size_t n,
+                                   const size_t* erasure_positions, size_t n_erasures, U256* coeffs_out,
+                                   size_t* ncoeffs_out);
+/* NonRobustShare::recover_secret (common/share/shamir.rs:199-239): plain Lagrange through ALL
+ * supplied shares + degree check (the RanDouSha verifier, ran_dou_sha/mod.rs:569-602). */
+ShareErrorCode hbmpc_nonrobust_recover_secret(hbmpc_ctx* ctx, const size_t* ids, const size_t* degrees,
+                                              const U256* vals, size_t S, size_t n, U256* coeffs_out,
+                                              size_t* ncoeffs_out, U256* secret_out);
+
+/* ==== a9/a11/a12/a13: element-wise share arithmetic of one party ============================
+ * All arrays hold N elements of ONE party (same id, same degree: the id/degree checks of
+ * common/mod.rs:167-300 are metadata and stay with the host mirror).  Host-pointer calls;
+ * hbmpc_dev_* twins take device pointers + stream. */
+/* triple_gen/triple_generation.rs:333-340: out = a*b - r2t */
+ShareErrorCode hbmpc_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, size_t N, U256* out);
+/* triple_generation.rs:196-208: c = rt + opened */
+ShareErrorCode hbmpc_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N, U256* c_out);
+/* mul/multiplication.rs:417-426: d_sh = a - x, e_sh = b - y */
+ShareErrorCode hbmpc_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x, const U256* y,
+                                        size_t N, U256* d_sh_out, U256* e_sh_out);
+/* multiplication.rs:57-100 finalize_mul: z = c - d*e - d*y - e*x  (d, e opened values) */
+ShareErrorCode hbmpc_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d,
+                                     const U256* e, size_t N, U256* z_out);
+/* fpmul/truncpr.rs:277-283: r_dash[i] = sum_{j<m} 2^j * r_bits[j][i]; r_bits[m][N] bit-major */
+ShareErrorCode hbmpc_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, U256* r_dash_out);
+/* truncpr.rs:275,294-297: open = (a + 2^(k-1)) + (2^m * r_int + r_dash) */
+ShareErrorCode hbmpc_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* r_int,
+                                        size_t k, size_t m, size_t N, U256* open_out);
+/* truncpr.rs:215-220 + fpmul/mod.rs:377-406: d = (a - ((c mod 2^m) - r_dash)) * (2^m)^-1 */
+ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open,
+                                      size_t m, size_t N, U256* d_out);
+
+ShareErrorCode hbmpc_dev_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, size_t N,
+                                      U256* out, void* stream);
+ShareErrorCode hbmpc_dev_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N, U256* c_out,
+                                         void* stream);
+ShareErrorCode hbmpc_dev_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x,
+                                            const U256* y, size_t N, U256* d_sh_out, U256* e_sh_out, void* stream);
+ShareErrorCode hbmpc_dev_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d,
+                                         const U256* e, size_t N, U256* z_out, void* stream);
+ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, U256* r_dash_out,
+                                       void* stream);
+ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* r_int,
+                                            size_t k, size_t m, size_t N, U256* open_out, void* stream);
+ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open,
+                                          size_t m, size_t N, U256* d_out, void* stream);
+
+/* ---- measurement aid: register-resident Montgomery-multiply loop (integer-ALU ceiling) ------
+ * Runs `iters` dependent modmuls in each of `threads` lanes, writes one U256 per lane to out_dev
+ * (so nothing is optimised away) and returns nothing else; time it with events on `stream`. */
+ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev, size_t threads, uint32_t iters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBMPC_HIP_H */
