@@ -208,6 +208,17 @@ ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const
 ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open,
                                           size_t m, size_t N, U256* d_out, void* stream);
 
+/* ==== a9: share (+, -, *) share of one party (common/mod.rs:167-300: Add, Sub, share_mul) ====
+ * op: 0 = a + b, 1 = a - b, 2 = a * b (element-wise, N elements). */
+ShareErrorCode hbmpc_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out);
+ShareErrorCode hbmpc_dev_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out, void* stream);
+
+/* ---- A/B aid: 0 = unsaturated 9x29-bit limbs (default, fast), 1 = saturated 8x32-bit limbs
+ * (the straightforward formulation; same results, kept as a cross-check). */
+ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
+/* test aid: 1 = route every shape through the generic (runtime-shaped) kernels */
+ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
+
 /* ---- measurement aid: register-resident Montgomery-multiply loop (integer-ALU ceiling) ------
  * Runs `iters` dependent modmuls in each of `threads` lanes, writes one U256 per lane to out_dev
  * (so nothing is optimised away) and returns nothing else; time it with events on `stream`. */

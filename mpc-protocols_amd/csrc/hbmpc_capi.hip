@@ -1,0 +1,471 @@
+// hbmpc_capi.hip -- the C ABI of include/hbmpc_hip.h: context, table cache, kernel dispatch.
+// There is no CPU data path here: host code only validates arguments, builds the small constant
+// tables (tables.hpp) and launches kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hbmpc_hip.h"
+#include "kernels_elem.hpp"
+#include "launchers.hpp"
+#include "tables.hpp"
+
+using namespace hbmpc;
+
+struct hbmpc_ctx {
+    int device = 0;
+    int impl = IMPL_U29;
+    bool force_generic = false;                    // tests: route every shape through the generic kernels
+    hipStream_t stream = nullptr;
+    std::mutex mu;                                 // serialises host-API calls and the table cache
+    std::map<std::string, uint32_t*> tables;       // device-resident constant tables
+    std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
+    std::string err;
+};
+
+static thread_local std::string g_err;
+
+#define HIP_TRY(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                            \
+            return e__ == hipErrorOutOfMemory ? HBMPC_OUT_OF_MEMORY : HBMPC_NO_DEVICE;                  \
+        }                                                                                               \
+    } while (0)
+
+static ShareErrorCode fail(hbmpc_ctx* ctx, ShareErrorCode rc, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return rc;
+}
+
+// ---- table cache -------------------------------------------------------------------------------
+template <class Build>
+static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build build, const uint32_t** out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        *out = it->second;
+        return ShareSuccess;
+    }
+    std::vector<uint32_t> host = build();
+    if (host.empty()) host.push_back(0);
+    uint32_t* dev = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dev, host.size() * 4));
+    HIP_TRY(ctx, hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    ctx->tables[key] = dev;
+    *out = dev;
+    return ShareSuccess;
+}
+static std::string key(const char* kind, std::initializer_list<size_t> v, int impl) {
+    std::string k = kind;
+    for (size_t x : v) k += ":" + std::to_string(x);
+    return k + "#" + std::to_string(impl);
+}
+
+static HFr rdev_value(int impl) {  // Rdev mod r as a field value: 2^256 (sat32) or 2^261 (u29)
+    HFr two = HFr::from_u64(2), p = HFr::one();
+    const int bits = impl == IMPL_U29 ? 261 : 256;
+    for (int i = 0; i < bits; ++i) p = p * two;
+    return p;
+}
+// r2: mont(x, r2) = x * Rdev (canonical -> Montgomery).  c0: a constant in device-constant form.
+// c1_plain: a canonical value in plain limb form (for load_const).
+static ElemConsts elem_consts(int impl, const HFr* c0 = nullptr, const HFr* c1_plain = nullptr) {
+    ElemConsts cs = {};
+    std::vector<uint32_t> v;
+    put_const(v, rdev_value(impl), impl);
+    for (int i = 0; i < impl_nl(impl); ++i) cs.r2[i] = v[i];
+    if (c0) {
+        v.clear();
+        put_const(v, *c0, impl);
+        for (int i = 0; i < impl_nl(impl); ++i) cs.c0[i] = v[i];
+    }
+    if (c1_plain) {
+        v.clear();
+        put_plain(v, *c1_plain, impl);
+        for (int i = 0; i < impl_nl(impl); ++i) cs.c1[i] = v[i];
+    }
+    return cs;
+}
+
+// ---- context -----------------------------------------------------------------------------------
+extern "C" const char* hbmpc_version(void) { return "hbmpc-hip 0.1 (gfx950)"; }
+
+extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out) {
+    if (!ctx_out) return InvalidInput;
+    *ctx_out = nullptr;
+    if (field_kind != Bls12_381Fr) return TypeMismatch;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        g_err = "hbmpc_create: no HIP device " + std::to_string(device) + " (this library has no CPU path)";
+        return HBMPC_NO_DEVICE;
+    }
+    hbmpc_ctx* ctx = new hbmpc_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_err = "hbmpc_create: hipSetDevice/hipStreamCreate failed";
+        delete ctx;
+        return HBMPC_NO_DEVICE;
+    }
+    const char* env = getenv("HBMPC_FIELD_IMPL");
+    if (env && std::string(env) == "sat32") ctx->impl = IMPL_SAT32;
+    *ctx_out = ctx;
+    return ShareSuccess;
+}
+extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->tables) (void)hipFree(kv.second);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+extern "C" const char* hbmpc_last_error(const hbmpc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
+    if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
+    ctx->impl = impl;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on) {
+    if (!ctx) return InvalidInput;
+    ctx->force_generic = on != 0;
+    return ShareSuccess;
+}
+
+extern "C" ShareErrorCode hbmpc_dev_alloc(hbmpc_ctx* ctx, size_t bytes, void** dptr_out) {
+    if (!ctx || !dptr_out) return InvalidInput;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(dptr_out, bytes ? bytes : 1));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipFree(dptr));
+    return ShareSuccess;
+}
+static hipStream_t pick(hbmpc_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+extern "C" ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick(ctx, stream)));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick(ctx, stream)));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipStreamSynchronize(pick(ctx, stream)));
+    return ShareSuccess;
+}
+
+// ---- a3 / a5: evaluation on the domain ---------------------------------------------------------
+static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, uint32_t* y,
+                                hipStream_t s) {
+    const size_t size = domain_size(n), dp1 = d + 1;
+    const int impl = ctx->impl;
+    if (impl == IMPL_U29 && size <= 16 && !ctx->force_generic) {
+        const uint32_t* tw;
+        ShareErrorCode rc = get_table(ctx, key("tw", {size}, impl), [&] { return build_twiddles(size, impl); }, &tw);
+        if (rc != ShareSuccess) return rc;
+        const int lg = ilog2(size), c = (int)dp1, nn = (int)n;
+        if (lg < 4 ? launch_fft1_lo(lg, c, x, G, nn, tw, y, s)
+                   : (launch_fft1_16a(c, x, G, nn, tw, y, s) || launch_fft1_16b(c, x, G, nn, tw, y, s) ||
+                      launch_fft1_16c(c, x, G, nn, tw, y, s) || launch_fft1_16d(c, x, G, nn, tw, y, s)))
+            return ShareSuccess;
+    } else if (impl == IMPL_U29 && size <= 256 && dp1 <= 32 && !ctx->force_generic) {
+        const size_t P = size / 16;
+        const uint32_t *tw16, *twist;
+        ShareErrorCode rc = get_table(ctx, key("tw", {16}, impl), [&] { return build_twiddles(16, impl); }, &tw16);
+        if (rc != ShareSuccess) return rc;
+        rc = get_table(ctx, key("twist", {size, dp1}, impl), [&] { return build_twist(size, P, dp1, impl); }, &twist);
+        if (rc != ShareSuccess) return rc;
+        const int c = (int)dp1, nn = (int)n, pp = (int)P;
+        if (launch_fftP_a(c, x, G, nn, pp, tw16, twist, y, s) || launch_fftP_b(c, x, G, nn, pp, tw16, twist, y, s) ||
+            launch_fftP_c(c, x, G, nn, pp, tw16, twist, y, s) || launch_fftP_d(c, x, G, nn, pp, tw16, twist, y, s) ||
+            launch_fftP_fold(c, x, G, nn, pp, tw16, twist, y, s))
+            return ShareSuccess;
+    }
+    const uint32_t* alpha;
+    ShareErrorCode rc = get_table(ctx, key("alpha", {n}, impl), [&] { return build_alpha(n, impl); }, &alpha);
+    if (rc != ShareSuccess) return rc;
+    launch_eval_generic(impl, x, G, (int)n, (int)dp1, alpha, y, s);
+    return ShareSuccess;
+}
+
+static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d, U256* y, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");  // :59-64
+    if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
+    if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
+    if (G == 0) return ShareSuccess;
+    if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    ShareErrorCode rc = eval_impl(ctx, (const uint32_t*)x, G, n, d, (uint32_t*)y, s);
+    if (rc != ShareSuccess) return rc;
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+
+extern "C" ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B, size_t n, size_t d,
+                                                   U256* shares_out, void* stream) {
+    return eval_dev(ctx, coeffs, B, n, d, shares_out, stream);
+}
+extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d,
+                                                      U256* y_out, void* stream) {
+    return eval_dev(ctx, x, G, n, d, y_out, stream);
+}
+
+// host wrapper helper: RAII device buffers on the ctx stream
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+static ShareErrorCode eval_host(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d, U256* y) {
+    if (!ctx) return InvalidInput;
+    if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
+    if (G == 0) return ShareSuccess;
+    if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    DevBuf dx, dy;
+    HIP_TRY(ctx, dx.alloc(G * (d + 1) * 32));
+    HIP_TRY(ctx, dy.alloc(G * n * 32));
+    HIP_TRY(ctx, hipMemcpyAsync(dx.p, x, G * (d + 1) * 32, hipMemcpyHostToDevice, ctx->stream));
+    ShareErrorCode rc = eval_dev(ctx, (const U256*)dx.p, G, n, d, (U256*)dy.p, nullptr);
+    if (rc != ShareSuccess) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(y, dy.p, G * n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B, size_t n, size_t d,
+                                               U256* shares_out) {
+    return eval_host(ctx, coeffs, B, n, d, shares_out);
+}
+extern "C" ShareErrorCode hbmpc_vandermonde_apply(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d,
+                                                  U256* y_out) {
+    return eval_host(ctx, x, G, n, d, y_out);
+}
+extern "C" ShareErrorCode hbmpc_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, U256* v_out) {
+    // common/share/mod.rs:31-45.  A constant table (rows [1, alpha_j, ..., alpha_j^d]), built where
+    // every other table of this library is built: on the host.
+    if (!ctx) return InvalidInput;
+    if (n == 0) return ShareSuccess;
+    if (!v_out) return fail(ctx, InvalidInput, "null buffer");
+    if (domain_size(n) > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
+    const std::vector<HFr> el = domain_elements(n, n);
+    for (size_t j = 0; j < n; ++j) {
+        HFr p = HFr::one();
+        for (size_t k = 0; k <= d; ++k) {
+            p.to_canon(v_out[j * (d + 1) + k].data);
+            p = p * el[j];
+        }
+    }
+    return ShareSuccess;
+}
+
+// ---- element-wise ------------------------------------------------------------------------------
+#define ELEM_PROLOGUE                                                           \
+    if (!ctx) return InvalidInput;                                              \
+    if (N == 0) return ShareSuccess;                                            \
+    HIP_TRY(ctx, hipSetDevice(ctx->device));                                    \
+    hipStream_t s = pick(ctx, stream);                                          \
+    const unsigned grid = (unsigned)((N + 255) / 256);                          \
+    (void)grid;
+
+#define BY_IMPL(KERNEL, ...)                                                                         \
+    do {                                                                                             \
+        if (ctx->impl == IMPL_U29)                                                                   \
+            hipLaunchKernelGGL((KERNEL<U29>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);             \
+        else                                                                                         \
+            hipLaunchKernelGGL((KERNEL<Sat32>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);           \
+        HIP_TRY(ctx, hipGetLastError());                                                             \
+    } while (0)
+
+#define W(p) ((const uint32_t*)(p))
+#define WO(p) ((uint32_t*)(p))
+
+extern "C" ShareErrorCode hbmpc_dev_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out,
+                                          void* stream) {
+    ELEM_PROLOGUE
+    if (op < 0 || op > 2) return fail(ctx, InvalidInput, "op must be 0 (add), 1 (sub) or 2 (mul)");
+    const ElemConsts cs = elem_consts(ctx->impl);
+    if (ctx->impl == IMPL_U29) {
+        if (op == 0) hipLaunchKernelGGL((k_binop<U29, OP_ADD>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+        if (op == 1) hipLaunchKernelGGL((k_binop<U29, OP_SUB>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+        if (op == 2) hipLaunchKernelGGL((k_binop<U29, OP_MUL>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+    } else {
+        if (op == 0) hipLaunchKernelGGL((k_binop<Sat32, OP_ADD>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+        if (op == 1) hipLaunchKernelGGL((k_binop<Sat32, OP_SUB>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+        if (op == 2) hipLaunchKernelGGL((k_binop<Sat32, OP_MUL>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t,
+                                                 size_t N, U256* out, void* stream) {
+    ELEM_PROLOGUE
+    const ElemConsts cs = elem_consts(ctx->impl);
+    BY_IMPL(k_triple_local, W(a), W(b), W(r2t), N, cs, WO(out));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N,
+                                                    U256* c_out, void* stream) {
+    ELEM_PROLOGUE
+    BY_IMPL(k_triple_finalize, W(rt), W(opened), N, WO(c_out));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x,
+                                                       const U256* y, size_t N, U256* d_sh, U256* e_sh,
+                                                       void* stream) {
+    ELEM_PROLOGUE
+    BY_IMPL(k_beaver_open, W(a), W(b), W(x), W(y), N, WO(d_sh), WO(e_sh));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y,
+                                                    const U256* d, const U256* e, size_t N, U256* z, void* stream) {
+    ELEM_PROLOGUE
+    const ElemConsts cs = elem_consts(ctx->impl);
+    BY_IMPL(k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N,
+                                                  U256* r_dash, void* stream) {
+    ELEM_PROLOGUE
+    if (m > 4096) return fail(ctx, InvalidInput, "m beyond the supported range");
+    const uint32_t* pow2;
+    const int impl = ctx->impl;
+    ShareErrorCode rc = get_table(ctx, key("pow2", {m}, impl), [&] { return build_pow2(m, impl); }, &pow2);
+    if (rc != ShareSuccess) return rc;
+    BY_IMPL(k_truncpr_rdash, W(r_bits), (int)m, N, pow2, WO(r_dash));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
+                                                       const U256* r_int, size_t k, size_t m, size_t N, U256* open_out,
+                                                       void* stream) {
+    if (ctx && k == 0) return fail(ctx, InvalidInput, "k must be >= 1 (2^(k-1))");
+    ELEM_PROLOGUE
+    const HFr two = HFr::from_u64(2);
+    const HFr p2m = two.pow_u64(m), p2k = two.pow_u64(k - 1);
+    const ElemConsts cs = elem_consts(ctx->impl, &p2m, &p2k);
+    BY_IMPL(k_truncpr_open, W(a), W(r_dash), W(r_int), N, cs, WO(open_out));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
+                                                     const U256* c_open, size_t m, size_t N, U256* d_out,
+                                                     void* stream) {
+    // fpmul/mod.rs:381-406 indexes bytes[m/8] when m % 8 != 0: out of bounds (a panic) from m = 257 on
+    if (ctx && m % 8 != 0 && m / 8 >= 32) return fail(ctx, InvalidInput, "m: bytes[m/8] out of bounds in the reference");
+    ELEM_PROLOGUE
+    const HFr inv = HFr::from_u64(2).pow_u64(m).inv();
+    const ElemConsts cs = elem_consts(ctx->impl, &inv);
+    BY_IMPL(k_truncpr_finalize, W(a), W(r_dash), W(c_open), (int)(m > 256 ? 256 : m), N, cs, WO(d_out));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev, size_t threads, uint32_t iters,
+                                                  void* stream) {
+    size_t N = threads;
+    ELEM_PROLOGUE
+    if (threads % 256) return fail(ctx, InvalidInput, "threads must be a multiple of 256");
+    const ElemConsts cs = elem_consts(ctx->impl);
+    BY_IMPL(k_modmul_ubench, WO(out_dev), iters, cs);
+    return ShareSuccess;
+}
+
+// host wrappers for the element-wise calls: n_in inputs of N elements (first input may be m*N), n_out outputs
+template <class Fn>
+static ShareErrorCode elem_host(hbmpc_ctx* ctx, std::initializer_list<std::pair<const U256*, size_t>> ins,
+                                std::initializer_list<std::pair<U256*, size_t>> outs, Fn fn) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::vector<DevBuf> bi(ins.size()), bo(outs.size());
+    std::vector<const U256*> pi;
+    std::vector<U256*> po;
+    size_t k = 0;
+    for (auto& in : ins) {
+        if (in.second && !in.first) return fail(ctx, InvalidInput, "null buffer");
+        HIP_TRY(ctx, bi[k].alloc(in.second * 32));
+        HIP_TRY(ctx, hipMemcpyAsync(bi[k].p, in.first, in.second * 32, hipMemcpyHostToDevice, ctx->stream));
+        pi.push_back((const U256*)bi[k].p);
+        ++k;
+    }
+    k = 0;
+    for (auto& o : outs) {
+        if (o.second && !o.first) return fail(ctx, InvalidInput, "null buffer");
+        HIP_TRY(ctx, bo[k].alloc(o.second * 32));
+        po.push_back((U256*)bo[k].p);
+        ++k;
+    }
+    ShareErrorCode rc = fn(pi, po);
+    if (rc != ShareSuccess) return rc;
+    k = 0;
+    for (auto& o : outs) {
+        HIP_TRY(ctx, hipMemcpyAsync(o.first, bo[k].p, o.second * 32, hipMemcpyDeviceToHost, ctx->stream));
+        ++k;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ShareSuccess;
+}
+typedef std::vector<const U256*> VI;
+typedef std::vector<U256*> VO;
+
+ShareErrorCode hbmpc_fr_op_host(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out) {
+    return elem_host(ctx, {{a, N}, {b, N}}, {{out, N}},
+                     [&](VI& i, VO& o) { return hbmpc_dev_fr_op(ctx, op, i[0], i[1], N, o[0], nullptr); });
+}
+extern "C" ShareErrorCode hbmpc_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out) {
+    return hbmpc_fr_op_host(ctx, op, a, b, N, out);
+}
+extern "C" ShareErrorCode hbmpc_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, size_t N,
+                                             U256* out) {
+    return elem_host(ctx, {{a, N}, {b, N}, {r2t, N}}, {{out, N}},
+                     [&](VI& i, VO& o) { return hbmpc_dev_triple_local(ctx, i[0], i[1], i[2], N, o[0], nullptr); });
+}
+extern "C" ShareErrorCode hbmpc_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N,
+                                                U256* c_out) {
+    return elem_host(ctx, {{rt, N}, {opened, N}}, {{c_out, N}},
+                     [&](VI& i, VO& o) { return hbmpc_dev_triple_finalize(ctx, i[0], i[1], N, o[0], nullptr); });
+}
+extern "C" ShareErrorCode hbmpc_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x,
+                                                   const U256* y, size_t N, U256* d_sh, U256* e_sh) {
+    return elem_host(ctx, {{a, N}, {b, N}, {x, N}, {y, N}}, {{d_sh, N}, {e_sh, N}}, [&](VI& i, VO& o) {
+        return hbmpc_dev_beaver_open_shares(ctx, i[0], i[1], i[2], i[3], N, o[0], o[1], nullptr);
+    });
+}
+extern "C" ShareErrorCode hbmpc_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y,
+                                                const U256* d, const U256* e, size_t N, U256* z) {
+    return elem_host(ctx, {{c, N}, {x, N}, {y, N}, {d, N}, {e, N}}, {{z, N}}, [&](VI& i, VO& o) {
+        return hbmpc_dev_beaver_finalize(ctx, i[0], i[1], i[2], i[3], i[4], N, o[0], nullptr);
+    });
+}
+extern "C" ShareErrorCode hbmpc_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, U256* r_dash) {
+    return elem_host(ctx, {{r_bits, m * N}}, {{r_dash, N}},
+                     [&](VI& i, VO& o) { return hbmpc_dev_truncpr_rdash(ctx, i[0], m, N, o[0], nullptr); });
+}
+extern "C" ShareErrorCode hbmpc_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
+                                                   const U256* r_int, size_t k, size_t m, size_t N, U256* open_out) {
+    return elem_host(ctx, {{a, N}, {r_dash, N}, {r_int, N}}, {{open_out, N}}, [&](VI& i, VO& o) {
+        return hbmpc_dev_truncpr_open_share(ctx, i[0], i[1], i[2], k, m, N, o[0], nullptr);
+    });
+}
+extern "C" ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
+                                                 const U256* c_open, size_t m, size_t N, U256* d_out) {
+    return elem_host(ctx, {{a, N}, {r_dash, N}, {c_open, N}}, {{d_out, N}}, [&](VI& i, VO& o) {
+        return hbmpc_dev_truncpr_finalize(ctx, i[0], i[1], i[2], m, N, o[0], nullptr);
+    });
+}
+
+#include "capi_recover.inc"

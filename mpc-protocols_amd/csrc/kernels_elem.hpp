@@ -1,0 +1,174 @@
+// kernels_elem.hpp -- element-wise share arithmetic of one party (reference rows a9, a11, a12, a13).
+// One lane per element, 32-byte coalesced loads/stores; all of these are HBM-bound.
+// Data x data products need Montgomery form on one side: mont(mont(a, R^2), b) = a*b.
+#pragma once
+#include "fr_sat.hpp"
+#include "fr_u29.hpp"
+
+namespace hbmpc {
+
+// device-constant-form scalars every element-wise kernel may need
+struct ElemConsts {
+    uint32_t r2[9];     // R^2 mod r  (mont(x, r2) = x*R: canonical -> Montgomery)
+    uint32_t c0[9];     // kernel-specific constant 0 (e.g. 2^m, (2^m)^-1) in device-constant form
+    uint32_t c1[9];     // kernel-specific constant 1 (e.g. 2^(k-1) as a canonical element in limb form)
+};
+
+#define HB_GID                                                                 \
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;            \
+    if (i >= N) return;
+
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
+
+// generic a (+,-,*) b  (common/mod.rs:167-300: share + share, share - share, share_mul)
+template <class F, int OP>
+__global__ __launch_bounds__(256) void k_binop(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                               size_t N, ElemConsts cs, uint32_t* __restrict__ out) {
+    using E = typename F::E;
+    HB_GID
+    const E x = F::load(a + i * 8), y = F::load(b + i * 8);
+    if constexpr (OP == OP_ADD) {
+        F::store_loose(out + i * 8, F::add(x, y));
+    } else if constexpr (OP == OP_SUB) {
+        F::store_loose(out + i * 8, F::template sub<2>(x, y));
+    } else {
+        const E xm = F::mulc(x, cs.r2);
+        F::store_lt2r(out + i * 8, F::mont(y, xm));
+    }
+}
+
+// triple_gen/triple_generation.rs:333-340:  out = a*b - r2t
+template <class F>
+__global__ __launch_bounds__(256) void k_triple_local(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                      const uint32_t* __restrict__ r2t, size_t N, ElemConsts cs,
+                                                      uint32_t* __restrict__ out) {
+    using E = typename F::E;
+    HB_GID
+    const E am = F::mulc(F::load(a + i * 8), cs.r2);
+    const E p = F::mont(F::load(b + i * 8), am);  // a*b, < 2r
+    F::store_loose(out + i * 8, F::template sub<2>(p, F::load(r2t + i * 8)));
+}
+// triple_generation.rs:196-208:  c = rt + opened
+template <class F>
+__global__ __launch_bounds__(256) void k_triple_finalize(const uint32_t* __restrict__ rt,
+                                                         const uint32_t* __restrict__ opened, size_t N,
+                                                         uint32_t* __restrict__ out) {
+    HB_GID
+    F::store_loose(out + i * 8, F::add(F::load(rt + i * 8), F::load(opened + i * 8)));
+}
+// mul/multiplication.rs:417-426:  d_sh = a - x, e_sh = b - y
+template <class F>
+__global__ __launch_bounds__(256) void k_beaver_open(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                     const uint32_t* __restrict__ x, const uint32_t* __restrict__ y,
+                                                     size_t N, uint32_t* __restrict__ d_sh,
+                                                     uint32_t* __restrict__ e_sh) {
+    HB_GID
+    F::store_loose(d_sh + i * 8, F::template sub<2>(F::load(a + i * 8), F::load(x + i * 8)));
+    F::store_loose(e_sh + i * 8, F::template sub<2>(F::load(b + i * 8), F::load(y + i * 8)));
+}
+// multiplication.rs:57-100 finalize_mul:  z = c - d*e - d*y - e*x
+template <class F>
+__global__ __launch_bounds__(256) void k_beaver_finalize(const uint32_t* __restrict__ c, const uint32_t* __restrict__ x,
+                                                         const uint32_t* __restrict__ y, const uint32_t* __restrict__ d,
+                                                         const uint32_t* __restrict__ e, size_t N, ElemConsts cs,
+                                                         uint32_t* __restrict__ z) {
+    using E = typename F::E;
+    HB_GID
+    const E dv = F::load(d + i * 8), ev = F::load(e + i * 8);
+    const E dm = F::mulc(dv, cs.r2), em = F::mulc(ev, cs.r2);  // Montgomery forms, normalised, < 2r
+    const E de = F::mont(ev, dm);                              // d*e
+    const E dy = F::mont(F::load(y + i * 8), dm);              // d*[y]
+    const E ex = F::mont(F::load(x + i * 8), em);              // e*[x]
+    E acc = F::template sub<4>(F::load(c + i * 8), de);
+    acc = F::template sub<4>(acc, dy);
+    acc = F::template sub<4>(acc, ex);  // < 13 r, limbs < 2^29 + 3*2^30
+    F::store_loose(z + i * 8, acc);
+}
+// fpmul/truncpr.rs:277-283:  r_dash[i] = sum_{j<m} 2^j * r_bits[j][i];  pow2[j] = 2^j device-constant form
+template <class F>
+__global__ __launch_bounds__(256) void k_truncpr_rdash(const uint32_t* __restrict__ r_bits, int m, size_t N,
+                                                       const uint32_t* __restrict__ pow2,
+                                                       uint32_t* __restrict__ out) {
+    using E = typename F::E;
+    HB_GID
+    typename F::Acc acc;
+    F::acc_zero(acc);
+    int pending = 0;
+    for (int j = 0; j < m; ++j) {
+        if (pending == F::MAX_DOT_TERMS) {
+            F::acc_fold(acc);
+            pending = 1;
+        }
+        F::acc_mac(acc, F::load(r_bits + ((size_t)j * N + i) * 8), pow2 + (size_t)j * F::NL);
+        ++pending;
+    }
+    F::acc_fold(acc);
+    const E r = F::acc_reduce(acc);
+    F::store_loose(out + i * 8, r);
+}
+// truncpr.rs:275,294-297:  open = (a + 2^(k-1)) + (2^m * r_int + r_dash);  cs.c0 = 2^m (const form), cs.c1 = 2^(k-1) limbs
+template <class F>
+__global__ __launch_bounds__(256) void k_truncpr_open(const uint32_t* __restrict__ a, const uint32_t* __restrict__ r_dash,
+                                                      const uint32_t* __restrict__ r_int, size_t N, ElemConsts cs,
+                                                      uint32_t* __restrict__ out) {
+    using E = typename F::E;
+    HB_GID
+    E acc = F::add(F::load(a + i * 8), F::load_const(cs.c1));
+    acc = F::add(acc, F::mulc(F::load(r_int + i * 8), cs.c0));
+    acc = F::add(acc, F::load(r_dash + i * 8));
+    F::store_loose(out + i * 8, acc);
+}
+// truncpr.rs:215-220 + fpmul/mod.rs:381-406:  d = (a - ((c mod 2^m) - r_dash)) * (2^m)^-1;  cs.c0 = (2^m)^-1
+template <class F>
+__global__ __launch_bounds__(256) void k_truncpr_finalize(const uint32_t* __restrict__ a,
+                                                          const uint32_t* __restrict__ r_dash,
+                                                          const uint32_t* __restrict__ c_open, int m, size_t N,
+                                                          ElemConsts cs, uint32_t* __restrict__ out) {
+    using E = typename F::E;
+    HB_GID
+    // low m bits of the canonical integer: mask the 8 little-endian words
+    const uint4 lo = *reinterpret_cast<const uint4*>(c_open + i * 8);
+    const uint4 hi = *reinterpret_cast<const uint4*>(c_open + i * 8 + 4);
+    uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int lo_bit = 32 * q;
+        uint32_t mask = m >= lo_bit + 32 ? 0xffffffffu : (m <= lo_bit ? 0u : ((1u << (m - lo_bit)) - 1u));
+        w[q] &= mask;
+    }
+    __attribute__((aligned(16))) uint32_t tmp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tmp[q] = w[q];
+    // c_mod < 2^m <= c < r for m < 256; m >= 256 keeps c itself.
+    E cm;
+    if constexpr (F::NL == 9) {
+        cm = U29::from_words(w);
+    } else {
+        cm = F::load(tmp);
+    }
+    E t = F::template sub<2>(F::load(r_dash + i * 8), cm);   // r_dash - c_mod  (= -(c_mod - r_dash)), + 2r
+    t = F::add(t, F::load(a + i * 8));                        // a - a'
+    F::store_lt2r(out + i * 8, F::mulc(t, cs.c0));
+}
+
+// register-resident Montgomery-multiply chain: the integer-ALU ceiling of the field implementation
+template <class F>
+__global__ __launch_bounds__(256) void k_modmul_ubench(uint32_t* __restrict__ out, uint32_t iters, ElemConsts cs) {
+    using E = typename F::E;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) w[q] = (uint32_t)(i * 2654435761u + q * 40503u + 1u);
+    w[7] &= 0x3fffffffu;
+    __attribute__((aligned(16))) uint32_t tmp[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tmp[q] = w[q];
+    E x = F::load(tmp), y = F::mulc(x, cs.r2);
+    for (uint32_t k = 0; k < iters; ++k) {
+        x = F::mont(x, y);
+        y = F::mont(y, x);
+    }
+    F::store_lt2r(out + i * 8, F::mont(x, y));
+}
+
+}  // namespace hbmpc

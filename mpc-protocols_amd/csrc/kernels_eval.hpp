@@ -1,0 +1,253 @@
+// kernels_eval.hpp -- polynomial evaluation on the roots-of-unity domain (reference rows a3 + a5):
+//   y[j][g] = sum_k x[g][k] * alpha_j^k,  j < n,  alpha_j = omega_size^j,  size = next_pow2(n)
+// This one linear map is both RobustShare::compute_shares (robust_interpolate.rs:52-82, a size-`size`
+// FFT of the zero-padded coefficients) and make_vandermonde+apply_vandermonde
+// (common/share/mod.rs:31-76, an n x (d+1) mat-vec).  Field arithmetic is exact, so any evaluation
+// order gives the reference's bits.
+//
+// Fast path: one lane per chunk, a zero-pruned radix-2 DIT FFT held entirely in registers
+// (<= 16 points per pass); domains larger than 16 are done in size/16 passes over the outputs
+// j = r (mod size/16): pass r twists the coefficients by omega^(r k), folds them mod x^16 - 1 and
+// runs the same 16-point FFT.  Pruning means a multiply only happens where the reference's FFT
+// would multiply two non-trivial values: n=16,d=5 costs 15 modmuls per secret (direct: 80),
+// n=31,d=10 costs 44 per chunk (direct: 341).
+// Layout: input chunk-major x[G][d+1] is staged through LDS with coalesced 16-byte loads (one
+// wave-tile = 64 chunks, rows padded by 16 B so the per-lane ds_read_b128 is bank-conflict free);
+// output party-major y[n][G]: a wave stores 2 KiB contiguous per party.
+#pragma once
+#include <utility>
+
+#include "fr_sat.hpp"
+#include "fr_u29.hpp"
+
+namespace hbmpc {
+
+// ---------------------------------------------------------------------------------------------
+// compile-time structure of the pruned FFT
+// ---------------------------------------------------------------------------------------------
+constexpr int bitrev_c(int log, int p) {
+    int r = 0;
+    for (int b = 0; b < log; ++b)
+        if (p & (1 << b)) r |= 1 << (log - 1 - b);
+    return r;
+}
+struct Bd {
+    int lbu;  // limb bound in units of 2^29 (0: element is identically zero)
+    int vb;   // value bound in units of r
+};
+constexpr int sub_k(int vb) {
+    return vb <= 1 ? 2 : vb <= 2 ? 4 : vb <= 4 ? 8 : vb <= 8 ? 16 : vb <= 16 ? 32 : vb <= 32 ? 64 : (1 << 20);
+}
+
+// bound of X[idx] after `stage` butterfly stages (stage 0 = bit-reversed inputs).  The code
+// generator below takes EXACTLY the same decisions (normalise u when lbu would pass 7, canonicalise
+// a lazy v before it is subtracted un-multiplied, normalise it before it is multiplied).
+constexpr Bd fft_bd(int LOG, int CNT, int LBU0, int VB0, int stage, int idx) {
+    if (stage == 0) return bitrev_c(LOG, idx) < CNT ? Bd{LBU0, VB0} : Bd{0, 0};
+    const int B = 1 << (stage - 1);
+    const int pos = idx & (2 * B - 1), k = pos & (B - 1);
+    const int iu = (idx & ~(2 * B - 1)) + k, iv = iu + B;
+    const bool upper = pos >= B;
+    const Bd u = fft_bd(LOG, CNT, LBU0, VB0, stage - 1, iu), v = fft_bd(LOG, CNT, LBU0, VB0, stage - 1, iv);
+    if (v.lbu == 0) return u;
+    // k != 0: t is a mulc output; k == 0: t is v itself when it is tight, else v canonicalised
+    const Bd t0 = k != 0 ? Bd{1, 2} : ((v.lbu == 1 && v.vb <= 2) ? v : Bd{1, 1});
+    const int K = sub_k(t0.vb);
+    if (u.lbu == 0) return upper ? Bd{2, K} : t0;
+    const Bd un = (u.lbu + 2 > 7) ? Bd{1, u.vb} : u;
+    return upper ? Bd{un.lbu + 2, un.vb + K} : Bd{un.lbu + t0.lbu, un.vb + t0.vb};
+}
+
+template <class F, int K>
+HB_DEV typename F::E sub_dispatch(const typename F::E& a, const typename F::E& b) {
+    return F::template sub<K>(a, b);
+}
+
+template <class F, int LOG, int CNT, int LBU0, int VB0, int STAGE, int IDX>
+HB_DEV void fft_bfly(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw) {
+    using E = typename F::E;
+    constexpr int S = 1 << LOG, B = 1 << STAGE;
+    constexpr int blk = IDX / B, k = IDX % B, iu = blk * 2 * B + k, iv = iu + B;
+    constexpr Bd bu = fft_bd(LOG, CNT, LBU0, VB0, STAGE, iu), bv = fft_bd(LOG, CNT, LBU0, VB0, STAGE, iv);
+    if constexpr (bv.lbu == 0) {
+        if constexpr (bu.lbu != 0) X[iv] = X[iu];
+    } else {
+        E t;
+        constexpr bool tight = bv.lbu == 1 && bv.vb <= 2;
+        if constexpr (k == 0) {
+            t = tight ? X[iv] : F::canon_loose(X[iv]);
+        } else {
+            const E vin = bv.lbu > 4 ? F::normalize(X[iv]) : X[iv];
+            t = F::mulc(vin, tw + (k * (S / (2 * B))) * F::NL);
+        }
+        constexpr int tvb = k == 0 ? (tight ? bv.vb : 1) : 2;
+        constexpr int K = sub_k(tvb);
+        static_assert(K <= 64, "value bound");
+        if constexpr (bu.lbu == 0) {
+            X[iu] = t;
+            X[iv] = sub_dispatch<F, K>(F::zero(), t);
+        } else {
+            const E u = (bu.lbu + 2 > 7) ? F::normalize(X[iu]) : X[iu];
+            X[iu] = F::add(u, t);
+            X[iv] = sub_dispatch<F, K>(u, t);
+        }
+    }
+}
+template <class F, int LOG, int CNT, int LBU0, int VB0, int STAGE, int... IDX>
+HB_DEV void fft_stage(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw,
+                      std::integer_sequence<int, IDX...>) {
+    (fft_bfly<F, LOG, CNT, LBU0, VB0, STAGE, IDX>(X, tw), ...);
+}
+template <class F, int LOG, int CNT, int LBU0, int VB0, int... STAGE>
+HB_DEV void fft_stages(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw,
+                       std::integer_sequence<int, STAGE...>) {
+    (fft_stage<F, LOG, CNT, LBU0, VB0, STAGE>(X, tw, std::make_integer_sequence<int, (1 << LOG) / 2>{}), ...);
+}
+// X: bit-reversed inputs (X[p] = c[bitrev(p)], zero where bitrev(p) >= CNT) -> natural-order
+// evaluations at omega_S^i.  tw[q] = omega_S^q (device-constant form), q < S/2.
+template <class F, int LOG, int CNT, int LBU0, int VB0>
+HB_DEV void fft_pruned(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw) {
+    if constexpr (LOG > 0) fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG>{});
+}
+template <int LOG, int CNT, int LBU0, int VB0>
+constexpr int fft_max_vb() {
+    int m = 0;
+    for (int i = 0; i < (1 << LOG); ++i) {
+        const Bd b = fft_bd(LOG, CNT, LBU0, VB0, LOG, i);
+        if (b.vb > m) m = b.vb;
+        if (b.lbu > 7) return 1 << 20;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tile: 64 chunks x DP1 elements, row pitch DP1*32 + 16 bytes
+// ---------------------------------------------------------------------------------------------
+constexpr int EVAL_TILE = 64;  // chunks per wave-tile (= one wavefront)
+
+HB_DEV int tile_pitch_words(int dp1) { return dp1 * 8 + 4; }
+
+// stage rows [g0, g0+64) of x[G][dp1] into LDS (coalesced 16-byte pieces; wave-uniform bounds)
+HB_DEV void stage_tile(uint32_t* __restrict__ lds, const uint32_t* __restrict__ x, size_t g0, size_t G, int dp1,
+                       int lane) {
+    const int pieces_per_row = dp1 * 2;
+    const size_t rows = G - g0 < (size_t)EVAL_TILE ? G - g0 : (size_t)EVAL_TILE;
+    const int total = (int)rows * pieces_per_row;
+    const uint4* src = reinterpret_cast<const uint4*>(x + g0 * (size_t)dp1 * 8);
+    const int pitch = tile_pitch_words(dp1);
+    for (int p = lane; p < total; p += EVAL_TILE) {
+        const uint4 v = src[p];
+        const int row = p / pieces_per_row, part = p - row * pieces_per_row;
+        *reinterpret_cast<uint4*>(lds + row * pitch + part * 4) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-pass kernel: size = 2^LOG <= 16, DP1 = CNT coefficients
+// ---------------------------------------------------------------------------------------------
+template <class F, int LOG, int CNT>
+__global__ __launch_bounds__(EVAL_TILE) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
+                                                         const uint32_t* __restrict__ tw, uint32_t* __restrict__ y) {
+    using E = typename F::E;
+    constexpr int S = 1 << LOG;
+    static_assert(CNT <= S && fft_max_vb<LOG, CNT, 1, 1>() <= 64, "bounds");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
+    stage_tile(lds, x, g0, G, CNT, lane);
+    __syncthreads();
+    const size_t g = g0 + lane;
+    if (g >= G) return;
+    const uint32_t* row = lds + lane * tile_pitch_words(CNT);
+    E X[S];
+#pragma unroll
+    for (int p = 0; p < S; ++p) {
+        const int k = bitrev_c(LOG, p);
+        if (k < CNT) X[p] = F::load(row + k * 8);
+    }
+    fft_pruned<F, LOG, CNT, 1, 1>(X, tw);
+#pragma unroll
+    for (int j = 0; j < S; ++j)
+        if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, X[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-pass kernel: size = 16 * P (P = 2, 4, 8, 16), DP1 <= 32 coefficients.
+// twist[r][k] = omega_size^(r k) (device-constant form), r < P, k < dp1 (row r = 0 unused).
+// CNT16 = min(dp1, 16).  FOLD = dp1 > 16.
+// ---------------------------------------------------------------------------------------------
+template <class F, int CNT16, bool FOLD>
+__global__ __launch_bounds__(EVAL_TILE) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+                                                         int P, const uint32_t* __restrict__ tw16,
+                                                         const uint32_t* __restrict__ twist,
+                                                         uint32_t* __restrict__ y) {
+    using E = typename F::E;
+    constexpr int Q = FOLD ? 2 : 1;
+    static_assert(fft_max_vb<4, CNT16, Q, Q>() <= 64 && fft_max_vb<4, CNT16, Q, 2 * Q>() <= 64, "bounds");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
+    stage_tile(lds, x, g0, G, dp1, lane);
+    __syncthreads();
+    const size_t g = g0 + lane;
+    if (g >= G) return;
+    const uint32_t* row = lds + lane * tile_pitch_words(dp1);
+    for (int r = 0; r < P; ++r) {
+        E X[16];
+        if (r == 0) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int k = bitrev_c(4, p);
+                if (k < CNT16) {
+                    X[p] = F::load(row + k * 8);
+                    if (FOLD && k + 16 < dp1) X[p] = F::add(X[p], F::load(row + (k + 16) * 8));
+                }
+            }
+            fft_pruned<F, 4, CNT16, Q, Q>(X, tw16);
+        } else {
+            const uint32_t* tr = twist + (size_t)r * dp1 * F::NL;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int k = bitrev_c(4, p);
+                if (k < CNT16) {
+                    X[p] = F::mulc(F::load(row + k * 8), tr + k * F::NL);
+                    if (FOLD && k + 16 < dp1)
+                        X[p] = F::add(X[p], F::mulc(F::load(row + (k + 16) * 8), tr + (k + 16) * F::NL));
+                }
+            }
+            fft_pruned<F, 4, CNT16, Q, 2 * Q>(X, tw16);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = r + P * i;
+            if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, X[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic kernel (any n <= 2^32 domain, any d): Horner per output, coefficients re-read from
+// global memory (chunk-major rows are L1/L2 resident while a lane walks its row).  O(n d) modmuls:
+// the slow, always-available path for shapes without a specialised kernel.
+// alpha[j] = omega^j in device-constant form.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+                                                      const uint32_t* __restrict__ alpha, uint32_t* __restrict__ y) {
+    using E = typename F::E;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint32_t* row = x + g * (size_t)dp1 * 8;
+    for (int j = 0; j < n; ++j) {
+        const uint32_t* a = alpha + (size_t)j * F::NL;
+        E acc = F::load(row + (size_t)(dp1 - 1) * 8);
+        for (int k = dp1 - 2; k >= 0; --k) {
+            acc = F::mulc(acc, a);  // < 2r, normalised
+            acc = F::add(acc, F::load(row + (size_t)k * 8));
+            // value < 3r, limbs < 2^30: fine as the next mulc input
+        }
+        F::store_loose(y + ((size_t)j * G + g) * 8, acc);
+    }
+}
+
+}  // namespace hbmpc

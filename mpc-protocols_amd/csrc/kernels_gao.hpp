@@ -1,0 +1,311 @@
+// kernels_gao.hpp -- the Byzantine fallback on the device: oec_decode + gao_rs_decode
+// (reference row a8, honeybadger/robust_interpolate/robust_interpolate.rs:456-628), run for the
+// chunks the optimistic verify flagged (robust_interpolate.rs:433-438).
+//
+// One workgroup per flagged chunk, one lane per polynomial coefficient, polynomials in LDS.
+// What depends only on positions is shared by all chunks and prepared on the host per OEC round
+// r (required = d+t+1+r lowest sender ids are "known", every other position is an erasure):
+//   g0_r  = prod_{i known} (x - alpha_i)            (= prod_{i<n}(x-alpha_i) / s(x), :474-495)
+//   LB_r  = Lagrange basis of the known points       (g1 = sum_j y_j LB_r[.][j], :483-491)
+// Per chunk: g1 by `required` dot products (one lane each), then the extended Euclidean algorithm
+// on (g0, g1) until deg < (required + k)/2 (:498-522), f = g / v (:527-537), and the acceptance
+// count (:613-622).  The EEA is run FRACTION-FREE (each elimination step is
+// lead(r1)*r0 - lead(r0)*x^s*r1, applied to the t-sequence too): (g, v) come out scaled by a common
+// nonzero factor, which changes neither degrees, nor g/v, nor whether the remainder is zero -- so
+// the only field inversion per chunk is lead(v)^-1 for the final exact division.
+// All LDS-resident coefficients are kept canonical (of Montgomery-form values), so "is zero" and
+// degrees are plain limb tests.
+#pragma once
+#include "../../include/hbmpc_hip.h"
+#include "fr_sat.hpp"
+#include "fr_u29.hpp"
+
+namespace hbmpc {
+
+struct GaoRound {
+    int required;        // number of known points (lowest `required` sorted sender ids)
+    int threshold;       // (required + k) / 2
+    uint32_t g0_off;     // offset (in u32) into `tables`: g0 coefficients [required+1], Montgomery limb form
+    uint32_t lb_off;     // LB[k][j] * R in device-constant form, [required][required]
+};
+struct GaoArgs {
+    const uint32_t* evals;     // [S][G] canonical
+    size_t G;
+    const int* rows;           // [S] row of the s-th lowest sender id
+    const uint32_t* alpha_s;   // [S] alpha of the s-th lowest sender id, device-constant form
+    const GaoRound* rounds;    // [n_rounds]
+    int n_rounds;
+    const uint32_t* tables;
+    int k;                     // message length d+1
+    int accept_min;            // d+t+1 (0: standalone gao_rs_decode, no acceptance count)
+    int out_width;             // coefficients written per chunk (d+1, or 1 for P(0)-only)
+    const uint32_t* flagged;   // compact list (null: chunk = block index)
+    const uint32_t* counters;  // [0] = number of flagged chunks (null: G)
+    uint32_t* out;             // [G][out_width]
+    uint32_t* ncoeffs;         // [G] or null
+    uint8_t* status;           // [G] or null
+    uint32_t* summary;         // hbmpc_recover_summary or null: {n_fallback, n_failed, first_failed, first_error}
+    const uint32_t* one_plain; // limbs of the integer 1 (mont(x, 1) leaves Montgomery form)
+    const uint32_t* r2;        // device-constant form of R (mont(x, r2) = x*R)
+    const uint32_t* inv_exp;   // r - 2 as 8 x u32
+};
+
+template <int BLOCK>
+HB_DEV int block_max(int v, int* scratch) {  // max over the block of a per-lane int (>= -1)
+    if constexpr (BLOCK == 64) {
+        (void)scratch;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int w = __shfl_xor(v, o);
+            v = w > v ? w : v;
+        }
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int w = __shfl_xor(v, o);
+            v = w > v ? w : v;
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+        __syncthreads();
+        int m = scratch[0];
+#pragma unroll
+        for (int i = 1; i < BLOCK / 64; ++i) m = scratch[i] > m ? scratch[i] : m;
+        return m;
+    }
+}
+
+template <class F>
+HB_DEV void lds_put(uint32_t* p, const typename F::E& x) {
+#pragma unroll
+    for (int i = 0; i < F::NL; ++i) p[i] = x.l[i];
+}
+template <class F>
+HB_DEV typename F::E lds_get(const uint32_t* p) {
+    typename F::E x;
+#pragma unroll
+    for (int i = 0; i < F::NL; ++i) x.l[i] = p[i];
+    return x;
+}
+
+// Fermat inverse of a canonical Montgomery-form value a (a*R): returns a^-1 * R, canonical.
+template <class F>
+__device__ __noinline__ typename F::E fr_inverse_mont(typename F::E a, const uint32_t* __restrict__ exp_words,
+                                                      const uint32_t* __restrict__ r2, const uint32_t* __restrict__ one_plain) {
+    using E = typename F::E;
+    E one;  // 1 in Montgomery form = mont(1_plain as data, r2) -> use load_const(one_plain) as data
+    one = F::cond_sub_r(F::mulc(F::load_const(one_plain), r2));
+    E acc = one;
+    for (int i = 255; i >= 0; --i) {
+        acc = F::cond_sub_r(F::mont(acc, acc));
+        if ((exp_words[i >> 5] >> (i & 31)) & 1) acc = F::cond_sub_r(F::mont(acc, a));
+    }
+    return acc;
+}
+
+// One block decodes chunks from the flagged list (block-stride loop).
+template <class F, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
+    using E = typename F::E;
+    constexpr int NL = F::NL;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // polynomials: BLOCK coefficients each
+    uint32_t* R0 = lds;
+    uint32_t* R1 = R0 + BLOCK * NL;
+    uint32_t* T0 = R1 + BLOCK * NL;
+    uint32_t* T1 = T0 + BLOCK * NL;
+    uint32_t* BC = T1 + BLOCK * NL;           // broadcast slots: 4 elements
+    int* iscr = reinterpret_cast<int*>(BC + 4 * NL);  // small int scratch (16 ints)
+    const int tid = threadIdx.x;
+    const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
+
+    for (size_t fi = blockIdx.x; fi < count; fi += gridDim.x) {
+        const size_t g = a.flagged ? (size_t)a.flagged[fi] : fi;
+        int result = DecodingError;  // oec_decode's error when no round succeeds (:625)
+        int out_len = 0;
+        bool done = false;
+        for (int rd = 0; rd < a.n_rounds && !done; ++rd) {
+            const GaoRound R = a.rounds[rd];
+            const int req = R.required;
+            __syncthreads();
+            // ---- r0 = g0, r1 = g1 = sum_j y_j LB[.][j], t0 = 0, t1 = 1 (Montgomery forms) --------
+            {
+                E v0 = F::zero(), v1 = F::zero();
+                if (tid <= req) v0 = F::load_const(a.tables + R.g0_off + (size_t)tid * NL);
+                if (tid < req) {
+                    typename F::Acc acc;
+                    F::acc_zero(acc);
+                    const uint32_t* row = a.tables + R.lb_off + (size_t)tid * req * NL;
+                    int pending = 0;
+                    for (int j = 0; j < req; ++j) {
+                        if (pending == F::MAX_DOT_TERMS) {
+                            F::acc_fold(acc);
+                            pending = 1;
+                        }
+                        F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[j] * a.G + g) * 8), row + (size_t)j * NL);
+                        ++pending;
+                    }
+                    F::acc_fold(acc);
+                    v1 = F::canon_loose(F::acc_reduce(acc));
+                }
+                lds_put<F>(R0 + tid * NL, v0);
+                lds_put<F>(R1 + tid * NL, v1);
+                lds_put<F>(T0 + tid * NL, F::zero());
+                E one = F::zero();
+                if (tid == 0) one = F::cond_sub_r(F::mulc(F::load_const(a.one_plain), a.r2));
+                lds_put<F>(T1 + tid * NL, one);
+            }
+            __syncthreads();
+            uint32_t *r0 = R0, *r1 = R1, *t0 = T0, *t1 = T1;
+            int d0 = req;  // deg g0
+            int d1 = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
+            // ---- EEA: while r1.degree() >= threshold (degree of the zero polynomial is 0) ---------
+            while ((d1 < 0 ? 0 : d1) >= R.threshold) {
+                // r0 <- r0 mod r1 (fraction-free), t0 <- t0 - q t1 (same combination); then swap
+                while (d0 >= d1) {
+                    const int sh = d0 - d1;
+                    const E lam = lds_get<F>(r1 + d1 * NL);  // lead(r1)
+                    const E mu = lds_get<F>(r0 + d0 * NL);   // lead(r0)
+                    E nr = F::mont(lds_get<F>(r0 + tid * NL), lam);
+                    E nt = F::mont(lds_get<F>(t0 + tid * NL), lam);
+                    if (tid >= sh) {
+                        nr = F::template sub<4>(nr, F::mont(lds_get<F>(r1 + (tid - sh) * NL), mu));
+                        nt = F::template sub<4>(nt, F::mont(lds_get<F>(t1 + (tid - sh) * NL), mu));
+                    }
+                    nr = F::canon_loose(nr);
+                    nt = F::canon_loose(nt);
+                    __syncthreads();
+                    lds_put<F>(r0 + tid * NL, nr);
+                    lds_put<F>(t0 + tid * NL, nt);
+                    __syncthreads();
+                    d0 = block_max<BLOCK>(F::is_zero_canon(nr) ? -1 : tid, iscr);
+                }
+                uint32_t* tmp = r0;
+                r0 = r1;
+                r1 = tmp;
+                tmp = t0;
+                t0 = t1;
+                t1 = tmp;
+                const int td = d0;
+                d0 = d1;
+                d1 = td;
+            }
+            // ---- f = g / v with g = r1, v = t1 (:524-537) ------------------------------------------
+            const int dg = d1;
+            const int dv = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(t1 + tid * NL)) ? -1 : tid, iscr);
+            bool ok = true;
+            int df = -1;  // degree of the quotient (-1: zero polynomial)
+            uint32_t* fq = t0;  // quotient coefficients are written over t0 (no longer needed)
+            if (dg < 0) {
+                // g == 0: quotient and remainder are zero -> the zero polynomial (degree() = 0 < k)
+                __syncthreads();
+                lds_put<F>(fq + tid * NL, F::zero());
+                __syncthreads();
+            } else if (dg < dv) {
+                ok = false;  // quotient 0, remainder g != 0
+            } else {
+                if (tid == 0) {
+                    const E inv = fr_inverse_mont<F>(lds_get<F>(t1 + dv * NL), a.inv_exp, a.r2, a.one_plain);
+                    lds_put<F>(BC, inv);
+                }
+                __syncthreads();
+                const E inv = lds_get<F>(BC);
+                __syncthreads();
+                lds_put<F>(fq + tid * NL, F::zero());
+                __syncthreads();
+                // long division of r1 (in place) by t1
+                for (int top = dg; top >= dv; --top) {
+                    const E lead = lds_get<F>(r1 + top * NL);
+                    const E c = F::cond_sub_r(F::mont(lead, inv));  // quotient coefficient
+                    const int sh = top - dv;
+                    E nr = lds_get<F>(r1 + tid * NL);
+                    if (tid >= sh && tid <= top)
+                        nr = F::canon_loose(F::template sub<4>(nr, F::mont(lds_get<F>(t1 + (tid - sh) * NL), c)));
+                    __syncthreads();
+                    lds_put<F>(r1 + tid * NL, nr);
+                    if (tid == sh) lds_put<F>(fq + sh * NL, c);
+                    __syncthreads();
+                }
+                const int drem = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
+                if (drem >= 0) ok = false;  // remainder must be zero
+                df = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(fq + tid * NL)) ? -1 : tid, iscr);
+                if ((df < 0 ? 0 : df) >= a.k) ok = false;  // quotient.degree() < k
+            }
+            if (ok && a.accept_min > 0) {
+                // matched = #{known j : f(alpha_j) == y_j} >= d+t+1 (:613-620)
+                int hit = 0;
+                if (tid < req) {
+                    const uint32_t* al = a.alpha_s + (size_t)tid * NL;
+                    E acc = F::zero();
+                    for (int kx = df; kx >= 0; --kx) {
+                        acc = F::mont(acc, al);
+                        acc = F::add(acc, lds_get<F>(fq + kx * NL));
+                    }
+                    const E val = F::cond_sub_r(F::mont(F::canon_loose(acc), a.one_plain));  // leave Montgomery form
+                    const E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.G + g) * 8);
+                    hit = F::eq_canon(val, ys) ? 1 : 0;
+                }
+                // block-wide sum via max of prefix counts is overkill: use LDS atomics
+                __syncthreads();
+                if (tid == 0) iscr[8] = 0;
+                __syncthreads();
+                if (hit) atomicAdd(&iscr[8], 1);
+                __syncthreads();
+                if (iscr[8] < a.accept_min) ok = false;
+                __syncthreads();
+            }
+            if (ok) {
+                // write the coefficients (canonical), zero padded to out_width
+                if (tid < a.out_width) {
+                    E c = F::zero();
+                    if (tid <= df) c = F::cond_sub_r(F::mont(lds_get<F>(fq + tid * NL), a.one_plain));
+                    F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * 8, c);
+                }
+                out_len = df + 1;
+                result = ShareSuccess;
+                done = true;
+            }
+        }
+        if (result != ShareSuccess && tid < a.out_width) {
+            F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * 8, F::zero());
+        }
+        if (tid == 0) {
+            if (a.ncoeffs) a.ncoeffs[g] = result == ShareSuccess ? (uint32_t)out_len : 0u;
+            if (a.status) a.status[g] = result == ShareSuccess ? 1 : (uint8_t)result;
+            if (a.summary) {
+                atomicAdd(&a.summary[0], 1u);
+                if (result != ShareSuccess) {
+                    atomicAdd(&a.summary[1], 1u);
+                    atomicMin(&a.summary[2], (uint32_t)g);
+                    a.summary[3] = (uint32_t)result;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// coefficients = LB * y for ONE instance (NonRobustShare::recover_secret: plain Lagrange through all
+// supplied shares, common/share/shamir.rs:199-239): lane k computes coefficient k.
+template <class F>
+__global__ __launch_bounds__(256) void k_matvec(const uint32_t* __restrict__ lb, const uint32_t* __restrict__ y,
+                                                int S, uint32_t* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    typename F::Acc acc;
+    F::acc_zero(acc);
+    int pending = 0;
+    for (int j = 0; j < S; ++j) {
+        if (pending == F::MAX_DOT_TERMS) {
+            F::acc_fold(acc);
+            pending = 1;
+        }
+        F::acc_mac(acc, F::load(y + (size_t)j * 8), lb + ((size_t)k * S + j) * F::NL);
+        ++pending;
+    }
+    F::acc_fold(acc);
+    F::store_loose(out + (size_t)k * 8, F::acc_reduce(acc));
+}
+
+}  // namespace hbmpc

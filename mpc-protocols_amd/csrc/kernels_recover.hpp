@@ -1,0 +1,138 @@
+// kernels_recover.hpp -- batch_recover_secret, optimistic path (reference row a7,
+// honeybadger/robust_interpolate/robust_interpolate.rs:284-443).
+//
+// One lane per chunk.  The tables depend only on the (sorted) sender ids, so they are built once on
+// the host and shared by every chunk -- exactly the reference's structure (:343-399):
+//   vm[s - m][i] = L_i(x_s)  for the verify points s = m .. needed-1   (rows s < m of the reference's
+//                  verify matrix are the identity: L_i(x_s) = [i == s]; they always pass in exact
+//                  arithmetic and are skipped -- same boolean)
+//   bc[k][i]     = coefficient k of L_i                                   (:423)
+// Per chunk: needed-m verify dot products + m (or 1, P(0)-only) recover dot products of length m,
+// each a lazy accumulation (81 carry-free mads per term) with ONE Montgomery reduction per dot.
+// Chunks that fail verification are flagged and appended to a compact list with one wave-aggregated
+// atomic per wave (ballot + popcount); the OEC/Gao kernel (kernels_gao.hpp) then decodes those.
+// Layout: evals[S][G] party-major -> a wave reads 2 KiB contiguous per sender row; outputs
+// chunk-major coeffs[G][m] (or secrets[G]).
+#pragma once
+#include "fr_sat.hpp"
+#include "fr_u29.hpp"
+
+namespace hbmpc {
+
+struct RecoverArgs {
+    const uint32_t* evals;   // [S][G] canonical
+    size_t G;
+    const int* rows;         // [needed] row (position in evals) of the s-th lowest sender id   (device)
+    int needed;              // d + t + 1
+    int m;                   // d + 1
+    const uint32_t* vm;      // [(needed - m)][m] device-constant form
+    const uint32_t* bc;      // [m][m]           device-constant form
+    uint32_t* out;           // [G][m] or [G]
+    uint32_t* ncoeffs;       // [G] or null
+    uint8_t* status;         // [G] or null
+    uint32_t* flagged;       // [G] compact list of failing chunks
+    uint32_t* counters;      // [0] = number of flagged chunks
+};
+
+template <class F>
+HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
+    const unsigned long long mask = __ballot(bad);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(a.counters, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (bad) a.flagged[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
+}
+
+// M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers.
+template <class F, int M, bool P0_ONLY>
+__global__ __launch_bounds__(256) void k_batch_recover(RecoverArgs a) {
+    using E = typename F::E;
+    static_assert(M <= F::MAX_DOT_TERMS, "dot length");
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = g < a.G;
+    const size_t gg = live ? g : a.G - 1;
+    E y[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8);
+    bool ok = true;
+    for (int s = M; s < a.needed; ++s) {
+        typename F::Acc acc;
+        F::acc_zero(acc);
+        const uint32_t* row = a.vm + (size_t)(s - M) * M * F::NL;
+#pragma unroll
+        for (int i = 0; i < M; ++i) F::acc_mac(acc, y[i], row + i * F::NL);
+        const E p = F::cond_sub_r(F::acc_reduce(acc));
+        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.G + gg) * 8);
+        ok = ok && F::eq_canon(p, ys);
+    }
+    flag_chunks<F>(live && !ok, g, a);
+    if (!live) return;
+    if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
+    if (!ok) return;
+    constexpr int OW = P0_ONLY ? 1 : M;
+    for (int k = 0; k < OW; ++k) {
+        typename F::Acc acc;
+        F::acc_zero(acc);
+        const uint32_t* row = a.bc + (size_t)k * M * F::NL;
+#pragma unroll
+        for (int i = 0; i < M; ++i) F::acc_mac(acc, y[i], row + i * F::NL);
+        F::store_lt2r(a.out + (g * OW + k) * 8, F::acc_reduce(acc));
+    }
+    if (a.ncoeffs) a.ncoeffs[g] = M;
+}
+
+// any m: inputs are re-read from global memory inside the dot products (they stay L2-resident).
+template <class F, bool P0_ONLY>
+__global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
+    using E = typename F::E;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = g < a.G;
+    const size_t gg = live ? g : a.G - 1;
+    const int M = a.m;
+    bool ok = true;
+    for (int s = M; s < a.needed; ++s) {
+        typename F::Acc acc;
+        F::acc_zero(acc);
+        const uint32_t* row = a.vm + (size_t)(s - M) * M * F::NL;
+        int pending = 0;
+        for (int i = 0; i < M; ++i) {
+            if (pending == F::MAX_DOT_TERMS) {
+                F::acc_fold(acc);
+                pending = 1;  // the folded columns count as less than one term
+            }
+            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8), row + i * F::NL);
+            ++pending;
+        }
+        F::acc_fold(acc);
+        const E p = F::canon_loose(F::acc_reduce(acc));
+        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.G + gg) * 8);
+        ok = ok && F::eq_canon(p, ys);
+    }
+    flag_chunks<F>(live && !ok, g, a);
+    if (!live) return;
+    if (a.status) a.status[g] = ok ? 0 : 0xff;
+    if (!ok) return;
+    const int OW = P0_ONLY ? 1 : M;
+    for (int k = 0; k < OW; ++k) {
+        typename F::Acc acc;
+        F::acc_zero(acc);
+        const uint32_t* row = a.bc + (size_t)k * M * F::NL;
+        int pending = 0;
+        for (int i = 0; i < M; ++i) {
+            if (pending == F::MAX_DOT_TERMS) {
+                F::acc_fold(acc);
+                pending = 1;
+            }
+            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8), row + i * F::NL);
+            ++pending;
+        }
+        F::acc_fold(acc);
+        F::store_loose(a.out + (g * (size_t)OW + k) * 8, F::acc_reduce(acc));
+    }
+    if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
+}
+
+}  // namespace hbmpc

@@ -1,0 +1,45 @@
+// launchers.hpp -- the kernel instantiations live in several translation units (tu_*.hip) so that
+// they compile in parallel; these are their entry points.  Each returns false when the requested
+// shape is not one it instantiates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "kernels_gao.hpp"
+#include "kernels_recover.hpp"
+
+namespace hbmpc {
+
+// single-pass pruned FFT, U29, size = 2^log <= 16, cnt = d+1 coefficients
+bool launch_fft1_lo(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_fft1_16a(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_fft1_16b(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_fft1_16c(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_fft1_16d(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+// multi-pass (size = 16 P), U29, dp1 <= 32
+bool launch_fftP_a(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
+                   uint32_t* y, hipStream_t s);
+bool launch_fftP_b(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
+                   uint32_t* y, hipStream_t s);
+bool launch_fftP_c(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
+                   uint32_t* y, hipStream_t s);
+bool launch_fftP_d(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
+                   uint32_t* y, hipStream_t s);
+bool launch_fftP_fold(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
+                      uint32_t* y, hipStream_t s);
+// generic Horner evaluation (impl: 0 = U29, 1 = Sat32)
+void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y,
+                         hipStream_t s);
+// batch recover, U29, register-resident m <= 16
+bool launch_recover_a(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+bool launch_recover_b(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+bool launch_recover_c(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+// OEC / Gao, matvec
+void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
+void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
+void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s);
+
+}  // namespace hbmpc

@@ -1,0 +1,177 @@
+// tables.hpp -- host-side construction of the small constant tables the kernels stage
+// (all depend only on (n, d, t, sender ids), never on batch data).
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/hbmpc_hip.h"
+#include "host_fr.hpp"
+
+namespace hbmpc {
+
+enum FieldImpl { IMPL_U29 = 0, IMPL_SAT32 = 1 };
+inline int impl_nl(int impl) { return impl == IMPL_U29 ? 9 : 8; }
+
+inline void put_const(std::vector<uint32_t>& out, const HFr& v, int impl) {
+    uint32_t tmp[9];
+    if (impl == IMPL_U29) {
+        v.to_u29(tmp);
+        out.insert(out.end(), tmp, tmp + 9);
+    } else {
+        v.to_sat32(tmp);
+        out.insert(out.end(), tmp, tmp + 8);
+    }
+}
+// canonical integer in the implementation's LIMB form (not Montgomery): for load_const of plain values
+inline void put_plain(std::vector<uint32_t>& out, const HFr& v, int impl) {
+    uint64_t c[4];
+    v.to_canon(c);
+    if (impl == IMPL_U29) {
+        for (int i = 0; i < 9; ++i) {
+            const int o = 29 * i, q = o >> 6, s = o & 63;
+            uint64_t x = c[q] >> s;
+            if (s > 64 - 29 && q + 1 < 4) x |= c[q + 1] << (64 - s);
+            out.push_back((uint32_t)(x & 0x1fffffffu));
+        }
+    } else {
+        for (int i = 0; i < 4; ++i) {
+            out.push_back((uint32_t)c[i]);
+            out.push_back((uint32_t)(c[i] >> 32));
+        }
+    }
+}
+
+inline size_t domain_size(size_t n) {
+    size_t s = 1;
+    while (s < n) s <<= 1;
+    return s;
+}
+inline int ilog2(size_t s) {
+    int l = 0;
+    while (((size_t)1 << l) < s) ++l;
+    return l;
+}
+// omega_size = 7^((r-1)/2^32) ^ (2^32/size)   (common/mod.rs:51-68 -> GeneralEvaluationDomain::new)
+inline bool domain_omega(size_t size, HFr* w) {
+    const int lg = ilog2(size);
+    if (lg > 32) return false;
+    const uint64_t rm1[4] = {HFr::MOD[0] - 1, HFr::MOD[1], HFr::MOD[2], HFr::MOD[3]};
+    uint64_t e[4];
+    e[0] = (rm1[0] >> 32) | (rm1[1] << 32);
+    e[1] = (rm1[1] >> 32) | (rm1[2] << 32);
+    e[2] = (rm1[2] >> 32) | (rm1[3] << 32);
+    e[3] = rm1[3] >> 32;
+    HFr root = HFr::from_u64(7).pow(e);
+    for (int i = lg; i < 32; ++i) root = root * root;
+    *w = root;
+    return true;
+}
+inline std::vector<HFr> domain_elements(size_t n, size_t count) {
+    HFr w;
+    domain_omega(domain_size(n), &w);
+    std::vector<HFr> el(count);
+    HFr p = HFr::one();
+    for (size_t j = 0; j < count; ++j) {
+        el[j] = p;
+        p = p * w;
+    }
+    return el;
+}
+
+// tw[q] = omega_S^q, q < max(S/2, 1)
+inline std::vector<uint32_t> build_twiddles(size_t S, int impl) {
+    std::vector<uint32_t> out;
+    HFr w;
+    domain_omega(S, &w);
+    HFr p = HFr::one();
+    for (size_t q = 0; q < std::max<size_t>(S / 2, 1); ++q) {
+        put_const(out, p, impl);
+        p = p * w;
+    }
+    return out;
+}
+// twist[r][k] = omega_size^(r k), r < P, k < dp1
+inline std::vector<uint32_t> build_twist(size_t size, size_t P, size_t dp1, int impl) {
+    std::vector<uint32_t> out;
+    HFr w;
+    domain_omega(size, &w);
+    HFr wr = HFr::one();
+    for (size_t r = 0; r < P; ++r) {
+        HFr p = HFr::one();
+        for (size_t k = 0; k < dp1; ++k) {
+            put_const(out, p, impl);
+            p = p * wr;
+        }
+        wr = wr * w;
+    }
+    return out;
+}
+inline std::vector<uint32_t> build_alpha(size_t n, int impl) {
+    std::vector<uint32_t> out;
+    for (const HFr& a : domain_elements(n, n)) put_const(out, a, impl);
+    return out;
+}
+inline std::vector<uint32_t> build_pow2(size_t m, int impl) {
+    std::vector<uint32_t> out;
+    HFr p = HFr::one(), two = HFr::from_u64(2);
+    for (size_t j = 0; j < m; ++j) {
+        put_const(out, p, impl);
+        p = p * two;
+    }
+    return out;
+}
+
+// Lagrange basis over the points xs (distinct): basis[i][k] = coefficient k of
+// L_i(x) = A(x) / ((x - x_i) A'(x_i)),  A = prod (x - x_j)     (robust_interpolate.rs:351-376)
+inline std::vector<std::vector<HFr>> lagrange_basis(const std::vector<HFr>& xs) {
+    const size_t m = xs.size();
+    std::vector<HFr> A(m + 1, HFr::zero());
+    A[0] = HFr::one();
+    size_t deg = 0;
+    for (const HFr& x : xs) {  // A *= (x - x_j)
+        const HFr nx = x.neg();
+        A[deg + 1] = A[deg];
+        for (size_t k = deg; k > 0; --k) A[k] = A[k] * nx + A[k - 1];
+        A[0] = A[0] * nx;
+        ++deg;
+    }
+    std::vector<std::vector<HFr>> basis(m, std::vector<HFr>(m, HFr::zero()));
+    for (size_t i = 0; i < m; ++i) {
+        // synthetic division of A by (x - x_i): q[m-1] = A[m], q[k-1] = A[k] + x_i q[k]
+        std::vector<HFr> q(m);
+        q[m - 1] = A[m];
+        for (size_t k = m - 1; k > 0; --k) q[k - 1] = A[k] + xs[i] * q[k];
+        HFr denom = HFr::one();  // A'(x_i) = prod_{j != i} (x_i - x_j)
+        for (size_t j = 0; j < m; ++j)
+            if (j != i) denom = denom * (xs[i] - xs[j]);
+        const HFr inv = denom.inv();
+        for (size_t k = 0; k < m; ++k) basis[i][k] = q[k] * inv;
+    }
+    return basis;
+}
+inline HFr horner(const std::vector<HFr>& p, const HFr& x) {
+    HFr acc = HFr::zero();
+    for (size_t k = p.size(); k-- > 0;) acc = acc * x + p[k];
+    return acc;
+}
+
+// batch_recover tables for id-sorted senders: vm[(needed-m)][m], bc[m][m]
+struct RecoverTables {
+    std::vector<uint32_t> vm, bc;
+};
+inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t, int impl) {
+    const size_t m = d + 1, needed = d + t + 1;
+    std::vector<HFr> el = domain_elements(n, n);
+    std::vector<HFr> xs(m);
+    for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[i]];
+    auto basis = lagrange_basis(xs);
+    RecoverTables T;
+    for (size_t s = m; s < needed; ++s)
+        for (size_t i = 0; i < m; ++i) put_const(T.vm, horner(basis[i], el[sorted_ids[s]]), impl);
+    for (size_t k = 0; k < m; ++k)
+        for (size_t i = 0; i < m; ++i) put_const(T.bc, basis[i][k], impl);
+    return T;
+}
+
+}  // namespace hbmpc

@@ -1,0 +1,18 @@
+#include <utility>
+
+#include "launchers.hpp"
+namespace hbmpc {
+template <int M, bool P0>
+static void one(const RecoverArgs& ra, unsigned grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_batch_recover<U29, M, P0>), dim3(grid), dim3(256), 0, s, ra);
+}
+template <int LO, int... I>
+static bool range(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s, std::integer_sequence<int, I...>) {
+    bool hit = false;
+    ((m == LO + I ? (p0 ? one<LO + I, true>(ra, grid, s) : one<LO + I, false>(ra, grid, s), hit = true) : false), ...);
+    return hit;
+}
+bool launch_recover_a(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s) {
+    return range<1>(m, p0, ra, grid, s, std::make_integer_sequence<int, 4>{});
+}
+}

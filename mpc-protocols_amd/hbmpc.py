@@ -1,0 +1,274 @@
+"""ctypes binding of libhbmpc_hip.so (the C ABI in include/hbmpc_hip.h) for tests and bench.py.
+
+This is plumbing, not a product path: the product is the shared library.  Arrays are numpy uint64
+with a trailing axis of 4 limbs (least-significant first) == U256[].  Every call goes through the
+C ABI; there is no fallback -- if the library or a GPU is missing, loading/creating fails loudly.
+
+Mirrors the reference interface for the path (SecretSharingScheme / free functions):
+  compute_shares        RobustShare::compute_shares        robust_interpolate.rs:52-82
+  make_vandermonde / vandermonde_apply                     common/share/mod.rs:31-76
+  batch_recover(_p0)    batch_recover_secret               robust_interpolate.rs:284-443
+  recover_secret        RobustShare::recover_secret        robust_interpolate.rs:94-157
+  gao_rs_decode                                            robust_interpolate.rs:456-538
+  nonrobust_recover_secret  NonRobustShare::recover_secret common/share/shamir.rs:199-239
+  triple_local/.../truncpr_finalize                        triple_gen, mul, fpmul element-wise math
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhbmpc_hip.so")
+_LIB = None
+
+
+class HbmpcError(RuntimeError):
+    pass
+
+
+def build(jobs: int = 8) -> str:
+    """Compile every HIP translation unit for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise HbmpcError(f"{LIB_PATH} is missing: run `make -C {_HERE}/csrc -j8` (or __graft_entry__.build())")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.hbmpc_last_error.restype = C.c_char_p
+        _LIB.hbmpc_version.restype = C.c_char_p
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))  # raw device pointer
+
+
+def u256(shape):
+    return np.zeros(tuple(shape) + (4,), dtype=np.uint64)
+
+
+def _sz(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+class Engine:
+    """One hbmpc_ctx on one GPU.  Host-pointer calls take/return numpy U256 arrays; the
+    dev_* calls take raw device pointers (ints, e.g. torch.Tensor.data_ptr()) and a stream."""
+
+    def __init__(self, device: int = 0, impl: str | None = None):
+        self.L = lib()
+        self.ctx = C.c_void_p()
+        rc = self.L.hbmpc_create(C.c_int(device), C.c_int(0), C.byref(self.ctx))
+        if rc != 0:
+            msg = self.L.hbmpc_last_error(None)
+            raise HbmpcError(f"hbmpc_create(device={device}) failed with code {rc}: {msg.decode() if msg else ''}")
+        if impl is not None:
+            self.set_impl(impl)
+
+    def close(self):
+        if self.ctx:
+            self.L.hbmpc_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self) -> str:
+        m = self.L.hbmpc_last_error(self.ctx)
+        return m.decode() if m else ""
+
+    def set_impl(self, impl: str):
+        rc = self.L.hbmpc_set_field_impl(self.ctx, C.c_int({"u29": 0, "sat32": 1}[impl]))
+        assert rc == 0
+
+    def set_force_generic(self, on: bool):
+        assert self.L.hbmpc_set_force_generic(self.ctx, C.c_int(1 if on else 0)) == 0
+
+    # ---- host-pointer API ----
+    def compute_shares(self, coeffs, n, d):
+        coeffs = np.ascontiguousarray(coeffs)
+        B = coeffs.shape[0]
+        out = u256((n, B))
+        rc = self.L.hbmpc_compute_shares(self.ctx, _p(coeffs), C.c_size_t(B), C.c_size_t(n), C.c_size_t(d), _p(out))
+        return rc, out
+
+    def make_vandermonde(self, n, d):
+        out = u256((n, d + 1))
+        rc = self.L.hbmpc_make_vandermonde(self.ctx, C.c_size_t(n), C.c_size_t(d), _p(out))
+        return rc, out
+
+    def vandermonde_apply(self, x, n, d):
+        x = np.ascontiguousarray(x)
+        G = x.shape[0]
+        out = u256((n, G))
+        rc = self.L.hbmpc_vandermonde_apply(self.ctx, _p(x), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), _p(out))
+        return rc, out
+
+    def batch_recover(self, sender_ids, evals, n, d, t):
+        evals = np.ascontiguousarray(evals)
+        S = len(sender_ids)
+        G = evals.shape[1] if evals.ndim == 3 else 0
+        out = u256((G, d + 1))
+        nco = np.zeros(G, dtype=np.uint32)
+        st = np.zeros(G, dtype=np.uint8)
+        rc = self.L.hbmpc_batch_recover(self.ctx, _p(_sz(sender_ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
+                                        C.c_size_t(n), C.c_size_t(d), C.c_size_t(t), _p(out), _p(nco), _p(st))
+        return rc, out, nco, st
+
+    def batch_recover_p0(self, sender_ids, evals, n, d, t):
+        evals = np.ascontiguousarray(evals)
+        S = len(sender_ids)
+        G = evals.shape[1] if evals.ndim == 3 else 0
+        out = u256((G,))
+        st = np.zeros(G, dtype=np.uint8)
+        rc = self.L.hbmpc_batch_recover_p0(self.ctx, _p(_sz(sender_ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
+                                           C.c_size_t(n), C.c_size_t(d), C.c_size_t(t), _p(out), _p(st))
+        return rc, out, st
+
+    def recover_secret(self, ids, degrees, vals, n, t):
+        vals = np.ascontiguousarray(vals)
+        S = len(ids)
+        cap = (int(degrees[0]) + 1) if S else 1
+        out = u256((max(cap, 1),))
+        nco = C.c_size_t(0)
+        sec = u256((1,))
+        rc = self.L.hbmpc_recover_secret(self.ctx, _p(_sz(ids)), _p(_sz(degrees)), _p(vals), C.c_size_t(S),
+                                         C.c_size_t(n), C.c_size_t(t), _p(out), C.byref(nco), _p(sec))
+        return rc, out[: nco.value], sec[0]
+
+    def gao_rs_decode(self, received, k, n, erasures):
+        received = np.ascontiguousarray(received)
+        out = u256((max(k, 1),))
+        nco = C.c_size_t(0)
+        rc = self.L.hbmpc_gao_rs_decode(self.ctx, _p(received), C.c_size_t(k), C.c_size_t(n), _p(_sz(erasures)),
+                                        C.c_size_t(len(erasures)), _p(out), C.byref(nco))
+        return rc, out[: nco.value]
+
+    def nonrobust_recover_secret(self, ids, degrees, vals, n):
+        vals = np.ascontiguousarray(vals)
+        S = len(ids)
+        out = u256((max(S, 1),))
+        nco = C.c_size_t(0)
+        sec = u256((1,))
+        rc = self.L.hbmpc_nonrobust_recover_secret(self.ctx, _p(_sz(ids)), _p(_sz(degrees)), _p(vals), C.c_size_t(S),
+                                                   C.c_size_t(n), _p(out), C.byref(nco), _p(sec))
+        return rc, out[: nco.value], sec[0]
+
+    def _ew(self, name, ins, n_out=1, extra=()):
+        ins = [np.ascontiguousarray(a) for a in ins]
+        N = ins[0].shape[0]
+        outs = [u256((N,)) for _ in range(n_out)]
+        args = [self.ctx] + [_p(a) for a in ins] + [C.c_size_t(e) for e in extra] + [C.c_size_t(N)] + [_p(o) for o in outs]
+        rc = getattr(self.L, name)(*args)
+        return (rc, *outs)
+
+    def fr_op(self, op, a, b):
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        out = u256((a.shape[0],))
+        rc = self.L.hbmpc_fr_op(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), _p(a), _p(b),
+                                C.c_size_t(a.shape[0]), _p(out))
+        return rc, out
+
+    def triple_local(self, a, b, r2t):
+        return self._ew("hbmpc_triple_local", [a, b, r2t])
+
+    def triple_finalize(self, rt, opened):
+        return self._ew("hbmpc_triple_finalize", [rt, opened])
+
+    def beaver_open_shares(self, a, b, x, y):
+        return self._ew("hbmpc_beaver_open_shares", [a, b, x, y], n_out=2)
+
+    def beaver_finalize(self, c, x, y, d, e):
+        return self._ew("hbmpc_beaver_finalize", [c, x, y, d, e])
+
+    def truncpr_rdash(self, r_bits, m):
+        r_bits = np.ascontiguousarray(r_bits)
+        N = r_bits.shape[1]
+        out = u256((N,))
+        rc = self.L.hbmpc_truncpr_rdash(self.ctx, _p(r_bits), C.c_size_t(m), C.c_size_t(N), _p(out))
+        return rc, out
+
+    def truncpr_open_share(self, a, r_dash, r_int, k, m):
+        return self._ew("hbmpc_truncpr_open_share", [a, r_dash, r_int], extra=(k, m))
+
+    def truncpr_finalize(self, a, r_dash, c_open, m):
+        return self._ew("hbmpc_truncpr_finalize", [a, r_dash, c_open], extra=(m,))
+
+    # ---- device-pointer API ----
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        rc = self.L.hbmpc_dev_alloc(self.ctx, C.c_size_t(nbytes), C.byref(p))
+        if rc != 0:
+            raise HbmpcError(f"hbmpc_dev_alloc({nbytes}) -> {rc}: {self.last_error()}")
+        return p.value
+
+    def dev_free(self, ptr: int):
+        self.L.hbmpc_dev_free(self.ctx, C.c_void_p(ptr))
+
+    def h2d(self, dptr: int, arr: np.ndarray, stream=0):
+        arr = np.ascontiguousarray(arr)
+        rc = self.L.hbmpc_memcpy_h2d(self.ctx, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes), C.c_void_p(stream))
+        assert rc == 0, self.last_error()
+
+    def d2h(self, arr: np.ndarray, dptr: int, stream=0):
+        assert arr.flags["C_CONTIGUOUS"]
+        rc = self.L.hbmpc_memcpy_d2h(self.ctx, _p(arr), C.c_void_p(dptr), C.c_size_t(arr.nbytes), C.c_void_p(stream))
+        assert rc == 0, self.last_error()
+
+    def sync(self, stream=0):
+        rc = self.L.hbmpc_stream_sync(self.ctx, C.c_void_p(stream))
+        if rc != 0:
+            raise HbmpcError(f"stream sync -> {rc}: {self.last_error()}")
+
+    def dev_compute_shares(self, coeffs_d, B, n, d, out_d, stream=0):
+        return self.L.hbmpc_dev_compute_shares(self.ctx, C.c_void_p(coeffs_d), C.c_size_t(B), C.c_size_t(n),
+                                               C.c_size_t(d), C.c_void_p(out_d), C.c_void_p(stream))
+
+    def dev_vandermonde_apply(self, x_d, G, n, d, y_d, stream=0):
+        return self.L.hbmpc_dev_vandermonde_apply(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),
+                                                  C.c_size_t(d), C.c_void_p(y_d), C.c_void_p(stream))
+
+    def dev_batch_recover(self, sender_ids, evals_d, G, n, d, t, out_d, nco_d=0, status_d=0, summary_d=0, stream=0,
+                          p0=False):
+        ids = _sz(sender_ids)
+        if p0:
+            return self.L.hbmpc_dev_batch_recover_p0(self.ctx, _p(ids), C.c_size_t(len(sender_ids)),
+                                                     C.c_void_p(evals_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
+                                                     C.c_size_t(t), C.c_void_p(out_d), C.c_void_p(status_d),
+                                                     C.c_void_p(summary_d), C.c_void_p(stream))
+        return self.L.hbmpc_dev_batch_recover(self.ctx, _p(ids), C.c_size_t(len(sender_ids)), C.c_void_p(evals_d),
+                                              C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(t),
+                                              C.c_void_p(out_d), C.c_void_p(nco_d), C.c_void_p(status_d),
+                                              C.c_void_p(summary_d), C.c_void_p(stream))
+
+    def dev_elem(self, name, ptrs, N, extra=(), stream=0):
+        args = [self.ctx] + [C.c_void_p(p) for p in ptrs[: name_inputs(name)]] + [C.c_size_t(e) for e in extra] + \
+               [C.c_size_t(N)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
+        return getattr(self.L, "hbmpc_dev_" + name)(*args)
+
+    def dev_modmul_ubench(self, out_d, threads, iters, stream=0):
+        return self.L.hbmpc_dev_modmul_ubench(self.ctx, C.c_void_p(out_d), C.c_size_t(threads), C.c_uint32(iters),
+                                              C.c_void_p(stream))
+
+
+_N_IN = {"triple_local": 3, "triple_finalize": 2, "beaver_open_shares": 4, "beaver_finalize": 5, "truncpr_rdash": 1,
+         "truncpr_open_share": 3, "truncpr_finalize": 3}
+
+
+def name_inputs(name):
+    return _N_IN[name]

@@ -1,0 +1,303 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the oracle (oracle/ is the
+checker only) -- golden vectors, seeded random inputs at sizes the oracle finishes in seconds,
+the reference's edge cases, and size-independent properties at BASELINE.json's full sizes.
+Bar: bit-exact (all arithmetic is integer mod r)."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import cref as O
+from oracle import spec as S
+from tests import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+R = S.R_MOD
+
+
+@pytest.fixture(scope="module")
+def eng():
+    pkg = load_package()
+    e = pkg.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(params=["u29", "u29-generic", "sat32"])
+def eng_all(request, eng):
+    mode = request.param
+    eng.set_impl("sat32" if mode == "sat32" else "u29")
+    eng.set_force_generic(mode == "u29-generic")
+    yield eng
+    eng.set_impl("u29")
+    eng.set_force_generic(False)
+
+
+def rnd(seed, *shape):
+    n = int(np.prod(shape))
+    return O.fill_random(seed, n).reshape(*shape, 4)
+
+
+def test_native_library_loaded(eng):
+    import os
+    maps = open("/proc/self/maps").read()
+    assert "libhbmpc_hip.so" in maps and os.path.exists("/dev/kfd")
+
+
+def test_golden_vectors(eng_all):
+    assert GU.run_all(eng_all) > 100
+
+
+def test_field_ops(eng_all):
+    e = eng_all
+    a, b = rnd(1, 3000), rnd(2, 3000)
+    edge = O.ints_to_u256([0, 1, 2, R - 1, R - 2, (1 << 255) % R, (1 << 254), R >> 1, (R >> 1) + 1, 0xFFFFFFFF,
+                           (1 << 232) - 1, (1 << 29) - 1, 1 << 29, R - (1 << 29)])
+    k = len(edge)
+    a[:k * k] = np.repeat(edge, k, axis=0)
+    b[:k * k] = np.tile(edge, (k, 1))
+    for op in ("add", "sub", "mul"):
+        rc, got = e.fr_op(op, a, b)
+        assert rc == 0
+        assert GU.eq(got, O.fr_binop(op, a, b)), op
+
+
+EVAL_SHAPES = [(1, 0), (2, 0), (2, 1), (3, 0), (3, 2), (4, 1), (4, 3), (5, 1), (7, 2), (8, 7), (10, 3), (13, 4), (16, 0),
+               (16, 5), (16, 10), (16, 15), (9, 8), (20, 6), (31, 10), (31, 20), (31, 30), (32, 31), (33, 5), (64, 21),
+               (100, 31), (100, 33), (128, 15), (255, 31), (255, 84), (200, 3)]
+
+
+@pytest.mark.parametrize("n,d", EVAL_SHAPES)
+def test_compute_shares_vs_oracle(eng, n, d):
+    G = 333 if n <= 64 else 70  # ragged tiles on purpose
+    x = rnd(1000 + 7 * n + d, G, d + 1)
+    x[0] = 0
+    x[1] = O.ints_to_u256([R - 1] * (d + 1))
+    rc, want = O.compute_shares(x, n, d)
+    assert rc == 0
+    rc, got = eng.compute_shares(x, n, d)
+    assert rc == 0, eng.last_error()
+    assert GU.eq(got, want)
+    rc, got2 = eng.vandermonde_apply(x, n, d)
+    assert rc == 0 and GU.eq(got2, want)
+
+
+@pytest.mark.parametrize("n,d", [(16, 5), (31, 10), (100, 33), (7, 2)])
+def test_compute_shares_other_impls(eng_all, n, d):
+    x = rnd(5 + n, 130, d + 1)
+    rc, want = O.compute_shares(x, n, d)
+    rc, got = eng_all.compute_shares(x, n, d)
+    assert rc == 0 and GU.eq(got, want)
+
+
+def test_eval_errors_and_empty(eng):
+    x = rnd(1, 2, 6)
+    assert eng.compute_shares(x, 5, 5)[0] == 4      # n <= degree
+    assert eng.compute_shares(x, 6, 5)[0] == 0
+    rc, out = eng.compute_shares(x[:0], 6, 5)        # empty batch
+    assert rc == 0 and out.shape == (6, 0, 4)
+    rc, v = eng.make_vandermonde(4, 9)               # make_vandermonde alone allows d >= n
+    rc0, v0 = O.make_vandermonde(4, 9)
+    assert rc == rc0 == 0 and GU.eq(v, v0)
+
+
+def _corrupt_case(n, t, d, G, seed, frac_bad, max_bad, ids=None):
+    """valid codewords from the oracle, then corrupt `frac_bad` of the chunks in 1..max_bad senders"""
+    x = rnd(seed, G, d + 1)
+    rc, y = O.compute_shares(x, n, d)
+    assert rc == 0
+    ids = list(range(n)) if ids is None else ids
+    ev = np.ascontiguousarray(y[ids])
+    rng = np.random.default_rng(seed)
+    bad_chunks = rng.choice(G, size=max(1, int(G * frac_bad)), replace=False) if frac_bad > 0 else []
+    for c in bad_chunks:
+        k = int(rng.integers(1, max_bad + 1))
+        for pos in rng.choice(len(ids), size=k, replace=False):
+            ev[pos, c, 0] ^= np.uint64(1 + int(rng.integers(0, 1000)))
+            if O.u256_to_ints(ev[pos, c]) >= R:  # keep canonical
+                ev[pos, c, 3] = 0
+    return x, ids, ev
+
+
+@pytest.mark.parametrize("n,t,d,G,frac,max_bad", [
+    (4, 1, 1, 500, 0.05, 1), (7, 2, 2, 700, 0.05, 3), (10, 3, 3, 600, 0.1, 4), (16, 5, 5, 2000, 0.02, 6),
+    (16, 5, 10, 1500, 0.02, 2), (31, 10, 10, 1500, 0.02, 11), (13, 4, 4, 300, 0.3, 5), (31, 10, 20, 200, 0.0, 0),
+    (64, 21, 21, 150, 0.05, 10), (100, 33, 33, 40, 0.1, 5), (70, 3, 30, 60, 0.1, 3)])
+def test_batch_recover_vs_oracle(eng, n, t, d, G, frac, max_bad):
+    x, ids, ev = _corrupt_case(n, t, d, G, 77 + n + d, frac, max_bad)
+    perm = np.random.default_rng(n).permutation(len(ids))  # arrival order
+    ids = [ids[i] for i in perm]
+    ev = np.ascontiguousarray(ev[perm])
+    rc0, co0, nco0, st0 = O.batch_recover(ids, ev, n, d, t)
+    rc, co, nco, st = eng.batch_recover(ids, ev, n, d, t)
+    assert rc == rc0, (rc, rc0, eng.last_error())
+    assert np.array_equal(st, st0)
+    assert GU.eq(co, co0) and np.array_equal(nco, nco0)
+    rc1, p0, st1 = eng.batch_recover_p0(ids, ev, n, d, t)
+    assert rc1 == rc0 and np.array_equal(st1, st0) and GU.eq(p0, co0[:, 0])
+    if frac > 0:
+        assert (st0 != 0).any()
+    ok = st0 <= 1
+    assert GU.eq(co[ok], x[ok])  # recovered coefficients == the original secrets
+
+
+@pytest.mark.parametrize("n,t,d", [(10, 3, 3), (16, 5, 10), (31, 10, 10)])
+def test_batch_recover_other_impls(eng_all, n, t, d):
+    x, ids, ev = _corrupt_case(n, t, d, 300, 5 + n, 0.05, t)
+    rc0, co0, nco0, st0 = O.batch_recover(ids, ev, n, d, t)
+    rc, co, nco, st = eng_all.batch_recover(ids, ev, n, d, t)
+    assert rc == rc0 and GU.eq(co, co0) and np.array_equal(nco, nco0) and np.array_equal(st, st0)
+
+
+def test_batch_recover_missing_senders_and_validation(eng):
+    n, t, d = 13, 4, 4
+    ids = [12, 0, 5, 7, 3, 9, 1, 10, 2, 11]  # 10 of 13 senders, arrival order
+    x, _, ev = _corrupt_case(n, t, d, 200, 9, 0.1, 2, ids=ids)
+    rc0, co0, nco0, st0 = O.batch_recover(ids, ev, n, d, t)
+    rc, co, nco, st = eng.batch_recover(ids, ev, n, d, t)
+    assert rc == rc0 and GU.eq(co, co0) and np.array_equal(st, st0) and np.array_equal(nco, nco0)
+    # validation order of robust_interpolate.rs:290-341
+    assert eng.batch_recover(ids, ev, 12, d, t)[0] == 4           # n < 3t+1
+    assert eng.batch_recover([], ev[:0], n, d, t)[0] == 4         # no evaluations
+    assert eng.batch_recover(ids, ev[:, :0], n, d, t)[0] == 4     # empty batch
+    assert eng.batch_recover([0, 0] + ids[2:], ev, n, d, t)[0] == 4   # duplicate
+    assert eng.batch_recover([13] + ids[1:], ev, n, d, t)[0] == 4     # out of range
+    assert eng.batch_recover(ids[:8], ev[:8], n, d, t)[0] == 4        # fewer than d+t+1
+
+
+def test_recover_secret_all_corruption_combinations(eng):
+    # robust_interpolate.rs:827-876 (n = 7, t = 2, every subset of <= t corrupted shares) + t+1 failures
+    from itertools import combinations
+    n, t = 7, 2
+    co = rnd(3, 1, t + 1)
+    co[0, 0] = O.ints_to_u256(42)
+    rc, sh = O.compute_shares(co, n, t)
+    vals = sh[:, 0]
+    for k in range(0, t + 2):
+        for idx in combinations(range(n), k):
+            v = vals.copy()
+            for i in idx:
+                v[i, 0] ^= np.uint64(999)
+            want = O.recover_secret(list(range(n)), [t] * n, v, n, t)
+            got = eng.recover_secret(list(range(n)), [t] * n, v, n, t)
+            assert got[0] == want[0], (idx, got[0], want[0])
+            if want[0] == 0:
+                assert GU.eq(got[1], want[1]) and GU.eq(got[2], want[2])
+                if k <= t:
+                    assert O.u256_to_ints(got[2]) == 42
+
+
+def test_elementwise_vs_oracle(eng_all):
+    e = eng_all
+    N = 1537
+    a, b, c, d, x = (rnd(s, N) for s in range(40, 45))
+    assert GU.eq(e.triple_local(a, b, c)[1], O.triple_local(a, b, c)[1])
+    assert GU.eq(e.triple_finalize(a, b)[1], O.triple_finalize(a, b)[1])
+    g, w = e.beaver_open_shares(a, b, c, d)[1:], O.beaver_open_shares(a, b, c, d)[1:]
+    assert GU.eq(g[0], w[0]) and GU.eq(g[1], w[1])
+    assert GU.eq(e.beaver_finalize(a, b, c, d, x)[1], O.beaver_finalize(a, b, c, d, x)[1])
+    for m in (1, 4, 16, 29, 40):
+        bits = rnd(50 + m, m, N)
+        assert GU.eq(e.truncpr_rdash(bits, m)[1], O.truncpr_rdash(bits, m)[1]), m
+    for k, m in ((16, 4), (32, 16), (1, 0), (250, 255), (64, 100)):
+        assert GU.eq(e.truncpr_open_share(a, b, c, k, m)[1], O.truncpr_open_share(a, b, c, k, m)[1])
+    for m in (0, 1, 7, 8, 9, 31, 32, 33, 64, 100, 254, 255, 256, 264):
+        assert GU.eq(e.truncpr_finalize(a, b, c, m)[1], O.truncpr_finalize(a, b, c, m)[1]), m
+    assert e.truncpr_finalize(a, b, c, 257)[0] == 4
+    assert e.truncpr_open_share(a, b, c, 0, 4)[0] == 4
+
+
+def test_beaver_mul_config1(eng):
+    """BASELINE config 1: n=4, t=1, 5 Beaver multiplications (tests/node_test.rs:447-453) as the
+    open/finalize algebra of all 4 parties, every step on the device."""
+    n, t, K = 4, 1, 5
+    rng = S.SplitMix64(12)
+    xs, ys, as_, bs = ([rng.fr() for _ in range(K)] for _ in range(4))
+
+    def share(vals):  # [n][K] shares of K secrets
+        co = O.ints_to_u256([[v, rng.fr()] for v in vals])
+        rc, sh = eng.compute_shares(co, n, t)
+        assert rc == 0
+        return sh
+    sx, sy, sa, sb = share(xs), share(ys), share(as_), share(bs)
+    sc = share([a * b % R for a, b in zip(as_, bs)])
+    dsh = np.stack([eng.beaver_open_shares(sa[i], sb[i], sx[i], sy[i])[1] for i in range(n)])
+    esh = np.stack([eng.beaver_open_shares(sa[i], sb[i], sx[i], sy[i])[2] for i in range(n)])
+    rc, d_open, _ = eng.batch_recover_p0(list(range(n)), dsh, n, t, t)
+    rc2, e_open, _ = eng.batch_recover_p0(list(range(n)), esh, n, t, t)
+    assert rc == rc2 == 0
+    assert O.u256_to_ints(d_open) == [(a - x) % R for a, x in zip(as_, xs)]
+    z = np.stack([eng.beaver_finalize(sc[i], sx[i], sy[i], d_open, e_open)[1] for i in range(n)])
+    rc, prod, _ = eng.batch_recover_p0(list(range(n)), z, n, t, t)
+    assert rc == 0 and O.u256_to_ints(prod) == [x * y % R for x, y in zip(xs, ys)]
+
+
+# ---- BASELINE.json full sizes: size-independent properties (the oracle would take minutes) -------
+def _dev_roundtrip(eng, n, t, d, G, seed, p0):
+    """encode on the device -> erase (drop senders) -> decode on the device -> equals the input"""
+    x = rnd(seed, G, d + 1)
+    xd = eng.dev_alloc(x.nbytes)
+    yd = eng.dev_alloc(n * G * 32)
+    eng.h2d(xd, x)
+    assert eng.dev_compute_shares(xd, G, n, d, yd) == 0, eng.last_error()
+    keep = list(range(n))[::-1][: d + t + 1 + (n - (d + t + 1)) // 2]  # erasures: drop the lowest ids, reversed arrival
+    ow = 1 if p0 else d + 1
+    od = eng.dev_alloc(G * ow * 32)
+    sd = eng.dev_alloc(G)
+    smd = eng.dev_alloc(16)
+    # gather the kept rows into a compact [S][G] array on the host side of the API (D2H/H2D: a test)
+    y = O.u256((n, G))
+    eng.d2h(y, yd)
+    eng.sync()
+    ev = np.ascontiguousarray(y[keep])
+    evd = eng.dev_alloc(ev.nbytes)
+    eng.h2d(evd, ev)
+    assert eng.dev_batch_recover(keep, evd, G, n, d, t, od, 0, sd, smd, p0=p0) == 0, eng.last_error()
+    out = O.u256((G, ow)) if not p0 else O.u256((G,))
+    st = np.zeros(G, dtype=np.uint8)
+    summ = np.zeros(4, dtype=np.uint32)
+    eng.d2h(out, od)
+    eng.d2h(st, sd)
+    eng.d2h(summ, smd)
+    eng.sync()
+    for p in (xd, yd, od, sd, smd, evd):
+        eng.dev_free(p)
+    assert summ[0] == 0 and summ[1] == 0 and not st.any()
+    assert GU.eq(out, x if not p0 else x[:, 0])
+    return x, y
+
+
+def test_full_size_cfg2_roundtrip_and_linearity(eng):
+    # config 2: n=16, t=5, 2^20 secrets
+    n, t, d, G = 16, 5, 5, 1 << 20
+    x, y = _dev_roundtrip(eng, n, t, d, G, 0xC0FFEE01, p0=True)
+    # checksum of checksums: sum over all secrets of share j == share j of the summed polynomial
+    ints = lambda a: O.u256_to_ints(a)  # noqa: E731
+    sub = slice(0, 4096)
+    xs = [sum(col) % R for col in zip(*[ints(row) for row in x[sub]])]
+    rc, ysum = eng.compute_shares(O.ints_to_u256([xs]), n, d)
+    assert rc == 0
+    for j in range(n):
+        assert sum(ints(y[j, sub])) % R == ints(ysum[j, 0])
+    # a sample of the full-size output against the oracle
+    rc, want = O.compute_shares(x[-2000:], n, d)
+    assert GU.eq(y[:, -2000:], want)
+
+
+def test_full_size_cfg3_roundtrip(eng):
+    # config 3: n=31, t=10, d=10, 2^20 chunks (encode = apply_vandermonde, decode = batch_recover_secret)
+    n, t, d, G = 31, 10, 10, 1 << 20
+    x, y = _dev_roundtrip(eng, n, t, d, G, 0xC0FFEE02, p0=False)
+    rc, want = O.vandermonde_apply(x[:1500], n, d)
+    assert GU.eq(y[:, :1500], want)
+
+
+def test_full_size_cfg4_triple_algebra(eng):
+    # config 4 shape (n=16, t=5, d=2t=10) on 2^18 triples of ONE simulated party + the open of a*b-r
+    n, t, G = 16, 5, 1 << 18
+    a, b, r2t = rnd(1, G), rnd(2, G), rnd(3, G)
+    rc, loc = eng.triple_local(a, b, r2t)
+    assert rc == 0
+    idx = np.random.default_rng(1).choice(G, 3000, replace=False)
+    assert GU.eq(loc[idx], O.triple_local(a[idx], b[idx], r2t[idx])[1])
+    rc, c = eng.triple_finalize(r2t, loc)
+    assert GU.eq(c[idx], O.fr_binop("mul", a[idx], b[idx]))  # (ab - r) + r == ab
