@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the Shamir share-arithmetic hot path on MI355X.
+
+Contract: python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run,
+one rank per GPU).  A "step" is one pass of RobustShare::compute_shares over one resident batch:
+BASELINE.json configs[1] -- n=16, t=5, 2^20 secrets, 256-bit Fr -- per GPU (weak scaling: batches are
+independent, there is no data-path collective).  Rank 0 prints ONE JSON line.
+
+  value      share-evals/s, whole job (n * B * N * K / max-over-ranks time), inputs resident in HBM
+  roofline   dominant kernel against the HBM roofline: algorithmic bytes per launch (704 B/secret)
+             / average launch duration measured with HIP events on the launch stream
+  cpu_baseline  the C restatement of the reference algorithm (oracle/, "port") timed on this box's
+             host cores on a bounded sample of the same workload (single thread: the reference runs
+             its arithmetic inline in one tokio task per party, no rayon)
+  extra      cfg3 encode/decode rates, element-wise rate, the register-resident modmul ceiling
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def shard_range(total: int, rank: int, world: int):
+    """contiguous batch shard of `rank`"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn):
+    """W untimed warmups, then EXACTLY K steps bracketed by barrier+sync; returns max-over-ranks seconds."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    dt = time.perf_counter() - t0
+    barrier_fn()
+    return max_reduce_fn(dt)
+
+
+def cpu_baseline(n, d, sample):
+    from oracle import cref  # the checker doubles as the reported CPU baseline ("port")
+    x = cref.fill_random(0xC0FFEE01, sample * (d + 1)).reshape(sample, d + 1, 4)
+    cref.compute_shares(x[:1024], n, d)
+    t0 = time.perf_counter()
+    rc, _ = cref.compute_shares(x, n, d)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": n * sample / dt, "unit": "share-evals/s", "cores": 1, "kind": "port",
+            "sample": f"compute_shares n={n} d={d} on {sample} secrets, single thread, "
+                      f"{os.path.basename(cref.build())}", "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log2-batch", type=int, default=20)
+    ap.add_argument("--cpu-sample-log2", type=int, default=22)
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--impl", default="u29", choices=["u29", "sat32"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    eng = pkg.Engine(local_rank, impl=args.impl)
+
+    n, t, d = 16, 5, 5
+    B = 1 << args.log2_batch  # per GPU (weak scaling)
+    from oracle import cref  # synthetic-input generator only (SplitMix64 -> mod r), same stream as the tests
+    lo, _ = shard_range(B * world, rank, world)
+    host = cref.fill_random(0xC0FFEE01 + rank, B * (d + 1)).reshape(B, d + 1, 4)
+    coeffs = torch.from_numpy(host.view(np.int64)).to(dev)          # [B][d+1][4] resident in HBM
+    shares = torch.empty((n, B, 4), dtype=torch.int64, device=dev)  # [n][B][4]
+    # an explicit (non-default) torch stream: its handle goes through the C ABI, so the kernels, the
+    # torch.cuda.Event timings and the copies above are all ordered on ONE stream
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
+
+    def step():
+        rc = eng.dev_compute_shares(coeffs.data_ptr(), B, n, d, shares.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"hbmpc_dev_compute_shares -> {rc}: {eng.last_error()}")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_reduce(x):
+        if world == 1:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    step()
+    torch.cuda.synchronize()
+    # parity spot-check of the benchmarked buffers (oracle as the checker, outside the timed region)
+    chk = shares[:, :512].cpu().numpy().view(np.uint64)
+    rc, want = cref.compute_shares(host[:512], n, d)
+    assert rc == 0 and np.array_equal(chk, want), "bench output differs from the oracle"
+
+    # kernel time with HIP events on the launch stream (same region as the timed loop, separate pass)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(args.warmup):
+        step()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_reduce)
+    value = n * B * world * args.steps / secs
+    algo_bytes = (d + 1 + n) * 32 * B
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "share-evals/sec (RobustShare::compute_shares, 256-bit Fr)",
+        "value": value, "unit": "share-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": secs / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"compute_shares n={n} t={t} batch=2^{args.log2_batch} secrets per GPU (BASELINE configs[1])",
+                   "field": "bls12-381 Fr", "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "field_impl": args.impl},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_eval_fft1<U29,4,6>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+    }
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            rec = json.load(open(tr)).get(f"compute_shares_n{n}_d{d}_B2^{args.log2_batch}_{args.impl}")
+            if rec:
+                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = rec["source"]
+        except Exception:
+            pass
+
+    if rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(n, d, 1 << args.cpu_sample_log2)
+        if not args.no_extra:
+            out["extra"] = extra_measurements(eng, torch, dev, stream, cref)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def extra_measurements(eng, torch, dev, stream, cref):
+    """Other rows of the path, timed with HIP events (not part of `value`)."""
+    res = {}
+
+    def ev_time(fn, reps=10, warm=2):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    # config 3: n=31, t=10, d=10, 2^20 chunks: encode (apply_vandermonde) and decode (batch_recover_secret)
+    n, t, d, G = 31, 10, 10, 1 << 20
+    host = cref.fill_random(0xC0FFEE02, G * (d + 1)).reshape(G, d + 1, 4)
+    x = torch.from_numpy(host.view(np.int64)).to(dev)
+    y = torch.empty((n, G, 4), dtype=torch.int64, device=dev)
+    co = torch.empty((G, d + 1, 4), dtype=torch.int64, device=dev)
+    st = torch.empty((G,), dtype=torch.uint8, device=dev)
+    summ = torch.zeros((4,), dtype=torch.int32, device=dev)
+    ids = list(range(n))
+    ms = ev_time(lambda: eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), stream))
+    res["cfg3_encode"] = {"chunks_per_s": G / ms * 1e3, "ms": ms, "GBps_algorithmic": (d + 1 + n) * 32 * G / ms / 1e6,
+                          "hbm_frac": (d + 1 + n) * 32 * G / ms / 1e6 / HBM_PEAK_GBS}
+    ms = ev_time(lambda: eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, co.data_ptr(), 0, st.data_ptr(),
+                                               summ.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert bool((co == x).all()) and int(st.max()) == 0
+    res["cfg3_decode"] = {"recons_per_s": G / ms * 1e3, "secrets_per_s": (d + 1) * G / ms * 1e3, "ms": ms,
+                          "GBps_algorithmic": (d + t + 1 + d + 1) * 32 * G / ms / 1e6,
+                          "hbm_frac": (d + t + 1 + d + 1) * 32 * G / ms / 1e6 / HBM_PEAK_GBS}
+    sec = torch.empty((G, 4), dtype=torch.int64, device=dev)
+    ms = ev_time(lambda: eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, sec.data_ptr(), 0, st.data_ptr(),
+                                               summ.data_ptr(), stream, p0=True))
+    res["cfg3_decode_p0"] = {"recons_per_s": G / ms * 1e3, "ms": ms,
+                             "GBps_algorithmic": (d + t + 1 + 1) * 32 * G / ms / 1e6}
+    del x, y, co, sec
+    # element-wise: triple_local on 2^22 elements (128 B/element)
+    N = 1 << 22
+    a = torch.from_numpy(cref.fill_random(1, N).view(np.int64)).to(dev)
+    b = torch.from_numpy(cref.fill_random(2, N).view(np.int64)).to(dev)
+    c = torch.from_numpy(cref.fill_random(3, N).view(np.int64)).to(dev)
+    o = torch.empty_like(a)
+    ms = ev_time(lambda: eng.dev_elem("triple_local", [a.data_ptr(), b.data_ptr(), c.data_ptr(), o.data_ptr()], N,
+                                      stream=stream))
+    res["triple_local"] = {"elems_per_s": N / ms * 1e3, "ms": ms, "GBps_algorithmic": 128 * N / ms / 1e6,
+                           "hbm_frac": 128 * N / ms / 1e6 / HBM_PEAK_GBS}
+    # integer-ALU ceiling: register-resident modmul chain (2 modmuls per iteration per lane)
+    for impl in ("u29", "sat32"):
+        eng.set_impl(impl)
+        threads, iters = 256 * 256 * 8, 2000
+        buf = torch.empty((threads, 4), dtype=torch.int64, device=dev)
+        ms = ev_time(lambda: eng.dev_modmul_ubench(buf.data_ptr(), threads, iters, stream), reps=3, warm=1)
+        res[f"modmul_per_s_{impl}"] = threads * (2 * iters + 2) / ms * 1e3
+    eng.set_impl("u29")
+    return res
+
+
+if __name__ == "__main__":
+    main()

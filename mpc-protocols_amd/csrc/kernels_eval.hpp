@@ -142,11 +142,51 @@ HB_DEV void stage_tile(uint32_t* __restrict__ lds, const uint32_t* __restrict__ 
     }
 }
 
+// statically indexed input/output passes (fold expressions: a partially unrolled loop would index
+// X[] dynamically and push the whole array to scratch)
+template <class F, int LOG, int CNT, int P>
+HB_DEV void load_plain_one(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ row, int dp1, bool fold) {
+    constexpr int k = bitrev_c(LOG, P);
+    if constexpr (k < CNT) {
+        X[P] = F::load(row + k * 8);
+        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::load(row + (k + 16) * 8));
+    }
+}
+template <class F, int LOG, int CNT, int... P>
+HB_DEV void load_plain(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ row, int dp1, bool fold,
+                       std::integer_sequence<int, P...>) {
+    (load_plain_one<F, LOG, CNT, P>(X, row, dp1, fold), ...);
+}
+template <class F, int CNT, int P>
+HB_DEV void load_twisted_one(typename F::E (&X)[16], const uint32_t* __restrict__ row,
+                             const uint32_t* __restrict__ tr, int dp1, bool fold) {
+    constexpr int k = bitrev_c(4, P);
+    if constexpr (k < CNT) {
+        X[P] = F::mulc(F::load(row + k * 8), tr + k * F::NL);
+        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::mulc(F::load(row + (k + 16) * 8), tr + (k + 16) * F::NL));
+    }
+}
+template <class F, int CNT, int... P>
+HB_DEV void load_twisted(typename F::E (&X)[16], const uint32_t* __restrict__ row, const uint32_t* __restrict__ tr,
+                         int dp1, bool fold, std::integer_sequence<int, P...>) {
+    (load_twisted_one<F, CNT, P>(X, row, tr, dp1, fold), ...);
+}
+template <class F, int S, int I>
+HB_DEV void store_one(const typename F::E (&X)[S], uint32_t* __restrict__ y, size_t G, size_t g, int r, int P, int n) {
+    const int j = r + P * I;
+    if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, X[I]);
+}
+template <class F, int S, int... I>
+HB_DEV void store_all(const typename F::E (&X)[S], uint32_t* __restrict__ y, size_t G, size_t g, int r, int P, int n,
+                      std::integer_sequence<int, I...>) {
+    (store_one<F, S, I>(X, y, G, g, r, P, n), ...);
+}
+
 // ---------------------------------------------------------------------------------------------
 // single-pass kernel: size = 2^LOG <= 16, DP1 = CNT coefficients
 // ---------------------------------------------------------------------------------------------
 template <class F, int LOG, int CNT>
-__global__ __launch_bounds__(EVAL_TILE) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
                                                          const uint32_t* __restrict__ tw, uint32_t* __restrict__ y) {
     using E = typename F::E;
     constexpr int S = 1 << LOG;
@@ -160,15 +200,9 @@ __global__ __launch_bounds__(EVAL_TILE) void k_eval_fft1(const uint32_t* __restr
     if (g >= G) return;
     const uint32_t* row = lds + lane * tile_pitch_words(CNT);
     E X[S];
-#pragma unroll
-    for (int p = 0; p < S; ++p) {
-        const int k = bitrev_c(LOG, p);
-        if (k < CNT) X[p] = F::load(row + k * 8);
-    }
+    load_plain<F, LOG, CNT>(X, row, CNT, false, std::make_integer_sequence<int, S>{});
     fft_pruned<F, LOG, CNT, 1, 1>(X, tw);
-#pragma unroll
-    for (int j = 0; j < S; ++j)
-        if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, X[j]);
+    store_all<F, S>(X, y, G, g, 0, 1, n, std::make_integer_sequence<int, S>{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -177,7 +211,7 @@ __global__ __launch_bounds__(EVAL_TILE) void k_eval_fft1(const uint32_t* __restr
 // CNT16 = min(dp1, 16).  FOLD = dp1 > 16.
 // ---------------------------------------------------------------------------------------------
 template <class F, int CNT16, bool FOLD>
-__global__ __launch_bounds__(EVAL_TILE) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
                                                          int P, const uint32_t* __restrict__ tw16,
                                                          const uint32_t* __restrict__ twist,
                                                          uint32_t* __restrict__ y) {
@@ -192,36 +226,17 @@ __global__ __launch_bounds__(EVAL_TILE) void k_eval_fftP(const uint32_t* __restr
     const size_t g = g0 + lane;
     if (g >= G) return;
     const uint32_t* row = lds + lane * tile_pitch_words(dp1);
-    for (int r = 0; r < P; ++r) {
+    {  // pass 0: no twist
         E X[16];
-        if (r == 0) {
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int k = bitrev_c(4, p);
-                if (k < CNT16) {
-                    X[p] = F::load(row + k * 8);
-                    if (FOLD && k + 16 < dp1) X[p] = F::add(X[p], F::load(row + (k + 16) * 8));
-                }
-            }
-            fft_pruned<F, 4, CNT16, Q, Q>(X, tw16);
-        } else {
-            const uint32_t* tr = twist + (size_t)r * dp1 * F::NL;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int k = bitrev_c(4, p);
-                if (k < CNT16) {
-                    X[p] = F::mulc(F::load(row + k * 8), tr + k * F::NL);
-                    if (FOLD && k + 16 < dp1)
-                        X[p] = F::add(X[p], F::mulc(F::load(row + (k + 16) * 8), tr + (k + 16) * F::NL));
-                }
-            }
-            fft_pruned<F, 4, CNT16, Q, 2 * Q>(X, tw16);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int j = r + P * i;
-            if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, X[i]);
-        }
+        load_plain<F, 4, CNT16>(X, row, dp1, FOLD, std::make_integer_sequence<int, 16>{});
+        fft_pruned<F, 4, CNT16, Q, Q>(X, tw16);
+        store_all<F, 16>(X, y, G, g, 0, P, n, std::make_integer_sequence<int, 16>{});
+    }
+    for (int r = 1; r < P; ++r) {
+        E X[16];
+        load_twisted<F, CNT16>(X, row, twist + (size_t)r * dp1 * F::NL, dp1, FOLD, std::make_integer_sequence<int, 16>{});
+        fft_pruned<F, 4, CNT16, Q, 2 * Q>(X, tw16);
+        store_all<F, 16>(X, y, G, g, r, P, n, std::make_integer_sequence<int, 16>{});
     }
 }
 

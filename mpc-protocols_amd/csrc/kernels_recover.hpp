@@ -46,11 +46,23 @@ HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
     if (bad) a.flagged[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
 }
 
-// M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers.
+// M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers; the
+// verify/recover tables are staged in LDS once per workgroup and read back as broadcasts (every
+// lane reads the same constant), which keeps them out of the scalar register file (holding a whole
+// row there made the compiler spill SGPRs through v_writelane/v_readlane).
 template <class F, int M, bool P0_ONLY>
 __global__ __launch_bounds__(256) void k_batch_recover(RecoverArgs a) {
     using E = typename F::E;
     static_assert(M <= F::MAX_DOT_TERMS, "dot length");
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    {
+        const int vm_words = (a.needed - M) * M * F::NL, bc_words = (P0_ONLY ? 1 : M) * M * F::NL;
+        for (int w = threadIdx.x; w < vm_words; w += 256) tab[w] = a.vm[w];
+        for (int w = threadIdx.x; w < bc_words; w += 256) tab[vm_words + w] = a.bc[w];
+        a.vm = tab;
+        a.bc = tab + vm_words;
+    }
+    __syncthreads();
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = g < a.G;
     const size_t gg = live ? g : a.G - 1;

@@ -4,7 +4,8 @@
 namespace hbmpc {
 template <int M, bool P0>
 static void one(const RecoverArgs& ra, unsigned grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_batch_recover<U29, M, P0>), dim3(grid), dim3(256), 0, s, ra);
+    const size_t lds = (size_t)((ra.needed - M) + (P0 ? 1 : M)) * M * U29::NL * 4;
+    hipLaunchKernelGGL((k_batch_recover<U29, M, P0>), dim3(grid), dim3(256), lds, s, ra);
 }
 template <int LO, int... I>
 static bool range(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s, std::integer_sequence<int, I...>) {

@@ -16,11 +16,20 @@ _LIB = None
 U64P = C.POINTER(C.c_uint64)
 
 
+def _cpu_has_v3() -> bool:
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return all(f in flags for f in (" bmi2", " adx", " avx2"))
+
+
 def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libhbmpc_oracle.so")
+    name = "libhbmpc_oracle_v3.so" if _cpu_has_v3() else "libhbmpc_oracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "hbmpc_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libhbmpc_oracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
     return so
 
 

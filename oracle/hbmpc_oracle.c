@@ -85,33 +85,35 @@ static inline int fr_is_zero(fr a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) 
 static inline int fr_eq(fr a, fr b) {
     return a.l[0] == b.l[0] && a.l[1] == b.l[1] && a.l[2] == b.l[2] && a.l[3] == b.l[3];
 }
-/* CIOS Montgomery product */
+/* CIOS Montgomery product, fully unrolled, with the "no-carry" shortcut ark-ff also uses for moduli
+ * whose top bit is free (r < 2^255): the running value stays below 2^256 + small, one spare word. */
+#define MAC(lo, hi, a, b, c, d)                         \
+    do {                                                \
+        u128 p__ = (u128)(a) * (b) + (c) + (d);         \
+        (lo) = (uint64_t)p__;                           \
+        (hi) = (uint64_t)(p__ >> 64);                   \
+    } while (0)
 static inline fr fr_mul(fr a, fr b) {
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 4; ++i) {
-        u128 c = 0;
-        for (int j = 0; j < 4; ++j) {
-            c += (u128)a.l[j] * b.l[i] + t[j];
-            t[j] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[4] = (uint64_t)c;
-        t[5] = (uint64_t)(c >> 64);
-        uint64_t m = t[0] * INV64;
-        c = (u128)m * MOD[0] + t[0];
-        c >>= 64;
-        for (int j = 1; j < 4; ++j) {
-            c += (u128)m * MOD[j] + t[j];
-            t[j - 1] = (uint64_t)c;
-            c >>= 64;
-        }
-        c += t[4];
-        t[3] = (uint64_t)c;
-        t[4] = t[5] + (uint64_t)(c >> 64);
-    }
-    fr o = {{t[0], t[1], t[2], t[3]}};
-    if (t[4] || geq_mod(o.l)) sub_mod(o.l);
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, c, c2, m, dump;
+#define ROUND(bi)                                   \
+    MAC(t0, c, a.l[0], bi, t0, 0);                  \
+    m = t0 * INV64;                                 \
+    MAC(dump, c2, m, MOD[0], t0, 0);                \
+    MAC(t1, c, a.l[1], bi, t1, c);                  \
+    MAC(t0, c2, m, MOD[1], t1, c2);                 \
+    MAC(t2, c, a.l[2], bi, t2, c);                  \
+    MAC(t1, c2, m, MOD[2], t2, c2);                 \
+    MAC(t3, c, a.l[3], bi, t3, c);                  \
+    MAC(t2, c2, m, MOD[3], t3, c2);                 \
+    t3 = c + c2;
+    ROUND(b.l[0])
+    ROUND(b.l[1])
+    ROUND(b.l[2])
+    ROUND(b.l[3])
+#undef ROUND
+    (void)dump;
+    fr o = {{t0, t1, t2, t3}};
+    if (geq_mod(o.l)) sub_mod(o.l);
     return o;
 }
 static inline fr fr_from_canon(const U256* u) {
