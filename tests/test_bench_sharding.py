@@ -1,0 +1,65 @@
+"""The N > 1 path of bench.py on CPU: world_size-2 gloo processes run the same shard / barrier /
+max-over-ranks timing logic the GPU ranks run (the compute step is replaced by a stub: there is no
+data-path collective to test, only the sharding and the reduction)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 1 << 20, (1 << 22) + 3):
+        for world in (1, 2, 3, 4, 8):
+            spans = [bench.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.002 * (rank + 1))  # rank 1 is slower: the reported time must be ITS time
+
+    def max_reduce(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    secs = bench.timed_steps(step, steps=5, warmup=2, sync_fn=lambda: None, barrier_fn=dist.barrier,
+                             max_reduce_fn=max_reduce)
+    lo, hi = bench.shard_range(1000, rank, world)
+    tot = torch.tensor([hi - lo], dtype=torch.int64)
+    dist.all_reduce(tot)
+    q.put((rank, len(calls), secs, int(tot.item())))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [7, 7]                 # W + K steps on every rank, exactly
+    assert res[0][2] == res[1][2]                        # both ranks report the max-over-ranks time
+    assert res[0][2] >= 5 * 0.004 * 0.9                  # ... which is the slow rank's
+    assert res[0][3] == 1000                             # shards cover the batch exactly once
