@@ -66,8 +66,8 @@ def cpu_baseline(n, d, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--cpu-sample-log2", type=int, default=22)
     ap.add_argument("--no-extra", action="store_true")

@@ -212,19 +212,21 @@ struct U29 {
         for (int i = 0; i < 9; ++i) r.l[i] = ((uint32_t)d[i] & ~neg) | (x.l[i] & neg);
         return r;
     }
-    // x loose (limbs < 2^32, value < 2^259): subtract q*r with q estimated from the top limbs so that
-    // the result is normalised and in [0, 2r); then the exact conditional subtraction.
-    static HB_DEV E canon_loose(const E& x) {
-        // top = floor(x / 2^232) up to an error of +-1; r_top = 0x73eda7 (floor(r / 2^232)).
+    // x loose (limbs < 2^32, value < 2^261): subtract q*r with q estimated from the top limbs.
+    // Result normalised and in [0, 2r); it is already < r unless its top limb reaches r's top limb
+    // (probability ~2^-19 per value: q is then one too small, or the value sits within 2^232 of r).
+    static HB_DEV E reduce_top(const E& x) {
+        // top = floor(x / 2^232) up to an error of +1; r_top = 0x73eda7 (floor(r / 2^232)).
         const uint32_t top = x.l[8] + (x.l[7] >> 29);
-        // q = floor(top / (r_top + 1)); top < 2^27.  2^45 / (r_top+1) rounded down, q error <= 1 low.
+        // q = floor(top / (r_top + 1)) <= floor(x / r), and >= floor(x / r) - 1
         constexpr uint64_t RECIP = (1ull << 45) / (uint64_t)(consts::U_MOD[8] + 1);
-        const uint32_t q = (uint32_t)(((uint64_t)top * RECIP) >> 45);
+        const int32_t nq = -(int32_t)(uint32_t)(((uint64_t)top * RECIP) >> 45);
         E y;
         int64_t acc = 0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            acc += (int64_t)x.l[i] - (int64_t)((uint64_t)q * consts::U_MOD[i]);
+            acc += (int64_t)x.l[i];
+            acc += (int64_t)nq * (int64_t)(int32_t)consts::U_MOD[i];
             if (i < 8) {
                 y.l[i] = (uint32_t)acc & MASK;
                 acc >>= 29;
@@ -232,7 +234,15 @@ struct U29 {
                 y.l[i] = (uint32_t)acc;
             }
         }
-        return cond_sub_r(y);
+        return y;
+    }
+    static HB_DEV bool maybe_ge_r(const E& y) { return y.l[8] >= consts::U_MOD[8]; }
+    static HB_DEV E canon_loose(const E& x) {
+        E y = reduce_top(x);
+        // exact: y_8 < r_8 implies y < r_8 * 2^232 <= r.  The full conditional subtraction runs only for
+        // waves in which some lane hits the rare case.
+        if (__builtin_expect(__any(maybe_ge_r(y)) != 0, 0)) y = cond_sub_r(y);
+        return y;
     }
     // canonical store of a value that is normalised and < 2r
     static HB_DEV void store_lt2r(uint32_t* __restrict__ p, const E& x) {
@@ -242,7 +252,7 @@ struct U29 {
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
         *reinterpret_cast<uint4*>(p + 4) = make_uint4(w[4], w[5], w[6], w[7]);
     }
-    // canonical store of any loose value < 2^259
+    // canonical store of any loose value < 2^261
     static HB_DEV void store_loose(uint32_t* __restrict__ p, const E& x) {
         const E c = canon_loose(x);
         uint32_t w[8];

@@ -127,7 +127,11 @@ constexpr int EVAL_TILE = 64;  // chunks per wave-tile (= one wavefront)
 
 HB_DEV int tile_pitch_words(int dp1) { return dp1 * 8 + 4; }
 
-// stage rows [g0, g0+64) of x[G][dp1] into LDS (coalesced 16-byte pieces; wave-uniform bounds)
+// stage rows [g0, g0+64) of x[G][dp1] into LDS: coalesced 16-byte pieces, wave-uniform bounds.
+// All of a lane's loads (NP = ceil(2*dp1) pieces, compile-time) are issued back-to-back BEFORE the first
+// wait, so one memory latency is exposed per tile -- a `load; s_waitcnt vmcnt(0); ds_write` loop exposed
+// twelve of them per wave (SQ_WAIT_ANY ~47 % of wave cycles, profiles/r01_pmc_compute_shares_v1.txt).
+template <int NP>
 HB_DEV void stage_tile(uint32_t* __restrict__ lds, const uint32_t* __restrict__ x, size_t g0, size_t G, int dp1,
                        int lane) {
     const int pieces_per_row = dp1 * 2;
@@ -135,10 +139,21 @@ HB_DEV void stage_tile(uint32_t* __restrict__ lds, const uint32_t* __restrict__ 
     const int total = (int)rows * pieces_per_row;
     const uint4* src = reinterpret_cast<const uint4*>(x + g0 * (size_t)dp1 * 8);
     const int pitch = tile_pitch_words(dp1);
-    for (int p = lane; p < total; p += EVAL_TILE) {
-        const uint4 v = src[p];
-        const int row = p / pieces_per_row, part = p - row * pieces_per_row;
-        *reinterpret_cast<uint4*>(lds + row * pitch + part * 4) = v;
+    for (int base = 0; base < total; base += NP * EVAL_TILE) {  // one trip unless dp1 > NP/2 (fold kernels)
+        uint4 v[NP];
+        int pc[NP];
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            // clamped: lanes past the end re-load (and re-write) the last piece -- no branches, no scratch
+            const int p = base + it * EVAL_TILE + lane;
+            pc[it] = p < total ? p : total - 1;
+            v[it] = src[pc[it]];
+        }
+#pragma unroll
+        for (int it = 0; it < NP; ++it) {
+            const int row = pc[it] / pieces_per_row, part = pc[it] - row * pieces_per_row;
+            *reinterpret_cast<uint4*>(lds + row * pitch + part * 4) = v[it];
+        }
     }
 }
 
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
-    stage_tile(lds, x, g0, G, CNT, lane);
+    stage_tile<2 * CNT>(lds, x, g0, G, CNT, lane);
     __syncthreads();
     const size_t g = g0 + lane;
     if (g >= G) return;
@@ -221,7 +236,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
-    stage_tile(lds, x, g0, G, dp1, lane);
+    stage_tile<FOLD ? 16 : 2 * CNT16>(lds, x, g0, G, dp1, lane);
     __syncthreads();
     const size_t g = g0 + lane;
     if (g >= G) return;

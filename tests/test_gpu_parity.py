@@ -72,6 +72,10 @@ def test_compute_shares_vs_oracle(eng, n, d):
     x = rnd(1000 + 7 * n + d, G, d + 1)
     x[0] = 0
     x[1] = O.ints_to_u256([R - 1] * (d + 1))
+    # constant polynomials whose shares sit in the rare branch of the canonical store (top limb == r's)
+    x[2] = O.ints_to_u256([R - 1] + [0] * d)
+    x[3] = O.ints_to_u256([(0x73EDA7 << 232) + 5] + [0] * d)
+    x[4] = O.ints_to_u256([(0x73EDA7 << 232) - 1] + [0] * d)
     rc, want = O.compute_shares(x, n, d)
     assert rc == 0
     rc, got = eng.compute_shares(x, n, d)
