@@ -124,6 +124,7 @@ struct Sat32 {
 
     static HB_DEV void acc_zero(Acc& A) { A.s = zero(); }
     static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) { A.s = add(A.s, mont(a, c)); }
+    static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[8]) { A.s = add(A.s, mont(a, c)); }
     static HB_DEV void acc_add_hi(Acc& A, const E& x) { A.s = add(A.s, x); }
     static HB_DEV void acc_fold(Acc&) {}
     static HB_DEV E acc_reduce(Acc& A) { return A.s; }

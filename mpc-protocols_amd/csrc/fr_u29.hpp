@@ -162,6 +162,32 @@ struct U29 {
 #pragma unroll
             for (int j = 0; j < 9; ++j) A.c[i + j] += (uint64_t)a.l[i] * c[j];
     }
+    // the same, with every product pinned to ONE in-place v_mad_u64_u32 (inline asm): hipcc otherwise
+    // re-associates the 81 mads into extra 64-bit temporaries to shorten dependency chains and, in
+    // kernels that already hold many elements in registers, spills the accumulators to scratch.
+    // Consecutive mads hit different columns (a column is revisited 8 instructions later), so the
+    // in-order stream has no dependency stalls to hide.
+    static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[9]) {
+        // one asm statement per data limb (9 mads): hipcc pads every inline-asm VALU statement with an
+        // s_nop, so fewer, larger statements
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            uint64_t carry_unused;  // the instructions' scalar carry-out (never read)
+            asm("v_mad_u64_u32 %0, %9, %10, %11, %0\n\t"
+                "v_mad_u64_u32 %1, %9, %10, %12, %1\n\t"
+                "v_mad_u64_u32 %2, %9, %10, %13, %2\n\t"
+                "v_mad_u64_u32 %3, %9, %10, %14, %3\n\t"
+                "v_mad_u64_u32 %4, %9, %10, %15, %4\n\t"
+                "v_mad_u64_u32 %5, %9, %10, %16, %5\n\t"
+                "v_mad_u64_u32 %6, %9, %10, %17, %6\n\t"
+                "v_mad_u64_u32 %7, %9, %10, %18, %7\n\t"
+                "v_mad_u64_u32 %8, %9, %10, %19, %8"
+                : "+v"(A.c[i]), "+v"(A.c[i + 1]), "+v"(A.c[i + 2]), "+v"(A.c[i + 3]), "+v"(A.c[i + 4]),
+                  "+v"(A.c[i + 5]), "+v"(A.c[i + 6]), "+v"(A.c[i + 7]), "+v"(A.c[i + 8]), "=&s"(carry_unused)
+                : "v"(a.l[i]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]),
+                  "v"(c[8]));
+        }
+    }
     // adds x * R (x loose): REDC then yields (... + x) -- a free "+ x" inside a dot product
     static HB_DEV void acc_add_hi(Acc& A, const E& x) {
 #pragma unroll

@@ -46,12 +46,48 @@ HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
     if (bad) a.flagged[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
 }
 
-// M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers; the
-// verify/recover tables are staged in LDS once per workgroup and read back as broadcasts (every
-// lane reads the same constant), which keeps them out of the scalar register file (holding a whole
-// row there made the compiler spill SGPRs through v_writelane/v_readlane).
+// M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers (9 M VGPRs).
+// The table constants are wave-uniform, so they are read through the scalar cache into SGPRs and fed
+// to v_mad_u64_u32 as its scalar operand: zero VGPRs, zero vector/LDS instructions.  The loads are
+// double-buffered by hand (constant i+1 is requested before term i's 81 mads) and fenced with
+// sched_barrier so that hipcc does not hoist a whole row into the scalar file (it then spills SGPRs
+// through v_writelane/v_readlane, ~700 extra instructions per dot product).
+template <class F>
+struct ConstRegs {
+    uint32_t w[F::NL];
+};
+HB_DEV const uint32_t* make_uniform(const uint32_t* p) {  // tells hipcc the address is wave-uniform -> s_load
+    const uint64_t u = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return (const uint32_t*)(((uint64_t)hi << 32) | lo);
+}
+template <class F>
+HB_DEV ConstRegs<F> load_uniform_const(const uint32_t* __restrict__ p) {
+    ConstRegs<F> c;
+#pragma unroll
+    for (int j = 0; j < F::NL; ++j) c.w[j] = p[j];
+    return c;
+}
+// one dot product of the register-resident y[0..M) with the constant row `row`
+template <class F, int M>
+HB_DEV typename F::E dot_row(const typename F::E (&y)[M], const uint32_t* __restrict__ row) {
+    typename F::Acc acc;
+    F::acc_zero(acc);
+    ConstRegs<F> cur = load_uniform_const<F>(row);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        ConstRegs<F> nxt = cur;
+        if (i + 1 < M) nxt = load_uniform_const<F>(row + (i + 1) * F::NL);
+        __builtin_amdgcn_sched_barrier(0);
+        F::acc_mac_pinned(acc, y[i], cur.w);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    }
+    return F::acc_reduce(acc);
+}
+
 template <class F, int M, bool P0_ONLY>
-__global__ __launch_bounds__(256) void k_batch_recover(RecoverArgs a) {
+__global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     using E = typename F::E;
     static_assert(M <= F::MAX_DOT_TERMS, "dot length");
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
@@ -71,12 +107,7 @@ __global__ __launch_bounds__(256) void k_batch_recover(RecoverArgs a) {
     for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8);
     bool ok = true;
     for (int s = M; s < a.needed; ++s) {
-        typename F::Acc acc;
-        F::acc_zero(acc);
-        const uint32_t* row = a.vm + (size_t)(s - M) * M * F::NL;
-#pragma unroll
-        for (int i = 0; i < M; ++i) F::acc_mac(acc, y[i], row + i * F::NL);
-        const E p = F::cond_sub_r(F::acc_reduce(acc));
+        const E p = F::cond_sub_r(dot_row<F, M>(y, a.vm + (size_t)(s - M) * M * F::NL));
         const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.G + gg) * 8);
         ok = ok && F::eq_canon(p, ys);
     }
@@ -85,14 +116,8 @@ __global__ __launch_bounds__(256) void k_batch_recover(RecoverArgs a) {
     if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
     if (!ok) return;
     constexpr int OW = P0_ONLY ? 1 : M;
-    for (int k = 0; k < OW; ++k) {
-        typename F::Acc acc;
-        F::acc_zero(acc);
-        const uint32_t* row = a.bc + (size_t)k * M * F::NL;
-#pragma unroll
-        for (int i = 0; i < M; ++i) F::acc_mac(acc, y[i], row + i * F::NL);
-        F::store_lt2r(a.out + (g * OW + k) * 8, F::acc_reduce(acc));
-    }
+    for (int k = 0; k < OW; ++k)
+        F::store_lt2r(a.out + (g * OW + k) * 8, dot_row<F, M>(y, a.bc + (size_t)k * M * F::NL));
     if (a.ncoeffs) a.ncoeffs[g] = M;
 }
 
