@@ -230,6 +230,8 @@ def extra_measurements(eng, torch, dev, stream, cref):
                                       stream=stream))
     res["triple_local"] = {"elems_per_s": N / ms * 1e3, "ms": ms, "GBps_algorithmic": 128 * N / ms / 1e6,
                            "hbm_frac": 128 * N / ms / 1e6 / HBM_PEAK_GBS}
+    del a, b, c, o
+    res.update(pipeline_measurements(eng, torch, dev, stream, ev_time))
     # integer-ALU ceiling: register-resident modmul chain (2 modmuls per iteration per lane)
     for impl in ("u29", "sat32"):
         eng.set_impl(impl)
@@ -238,6 +240,71 @@ def extra_measurements(eng, torch, dev, stream, cref):
         ms = ev_time(lambda: eng.dev_modmul_ubench(buf.data_ptr(), threads, iters, stream), reps=3, warm=1)
         res[f"modmul_per_s_{impl}"] = threads * (2 * iters + 2) / ms * 1e3
     eng.set_impl("u29")
+    return res
+
+
+def _rand_fr(torch, dev, *shape):
+    """uniform-ish canonical field elements generated on the device (limb 3 below r's top limb)"""
+    lo = torch.randint(0, 1 << 62, shape + (3,), dtype=torch.int64, device=dev)
+    hi = torch.randint(0, 0x73EDA753299D7D48, shape + (1,), dtype=torch.int64, device=dev)
+    return torch.cat([lo, hi], dim=-1).contiguous()
+
+
+def _share_on_device(eng, torch, dev, stream, secrets, n, d, out_ptr):
+    """[n][N] degree-d sharings of `secrets` written to out_ptr, by the compute_shares kernel itself"""
+    N = secrets.shape[0]
+    co = _rand_fr(torch, dev, N, d + 1)
+    co[:, 0] = secrets
+    rc = eng.dev_compute_shares(co.data_ptr(), N, n, d, out_ptr, stream)
+    assert rc == 0, eng.last_error()
+    torch.cuda.synchronize()
+
+
+def pipeline_measurements(eng, torch, dev, stream, ev_time):
+    """BASELINE configs 4 and 5 as device-resident replays of all n parties on ONE GPU (mpc-protocols_amd/pipelines.py)."""
+    from __graft_entry__ import load_package
+    pl = load_package().pipelines
+    res = {}
+    # config 4: triple_gen, n=16, t=5, 2^22 triples (rounded down to a multiple of 2t+1)
+    n, t = 16, 5
+    N = ((1 << 22) // (2 * t + 1)) * (2 * t + 1)
+    tg = pl.TripleGen(eng, n, t, N, stream)
+    a, b, r = (_rand_fr(torch, dev, N) for _ in range(3))
+    _share_on_device(eng, torch, dev, stream, a, n, t, tg.a)
+    _share_on_device(eng, torch, dev, stream, b, n, t, tg.b)
+    _share_on_device(eng, torch, dev, stream, r, n, t, tg.rt)
+    _share_on_device(eng, torch, dev, stream, r, n, 2 * t, tg.r2t)
+    tg.run(check=True)  # one checked run: every decode reports zero failures
+    ms = ev_time(lambda: tg.run(check=False), reps=5, warm=1)
+    res["cfg4_triple_gen_16_parties"] = {"triples_per_s": N / ms * 1e3, "ms": ms, "triples": N,
+                                         "note": "all 16 simulated parties on one GPU: local mul, encode, 16 P(0) decodes, reveal decode, finalize"}
+    tg.close()
+    del a, b, r
+    # config 5: fpmul, n=16, t=5, 2^18 elements, (k, f) = (16, 4)
+    N, k, m = 1 << 18, 16, 4
+    fp = pl.FpMul(eng, n, t, N, k, m, stream)
+    x = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    y = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    x[:, 0] = torch.randint(0, 1 << 7, (N,), device=dev)
+    y[:, 0] = torch.randint(0, 1 << 7, (N,), device=dev)
+    ta, tb = _rand_fr(torch, dev, N), _rand_fr(torch, dev, N)
+    tc = torch.empty_like(ta)
+    assert eng.dev_fr_op("mul", ta.data_ptr(), tb.data_ptr(), N, tc.data_ptr(), stream) == 0
+    rint = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    rint[:, 0] = torch.randint(0, 1 << 40, (N,), device=dev)
+    for sec, ptr in ((x, fp.x), (y, fp.y), (ta, fp.ta), (tb, fp.tb), (tc, fp.tc), (rint, fp.rint)):
+        _share_on_device(eng, torch, dev, stream, sec, n, t, ptr)
+    tmp = torch.empty((n, N, 4), dtype=torch.int64, device=dev)
+    for j in range(m):  # r_bits[party][bit][N]
+        bit = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+        bit[:, 0] = torch.randint(0, 2, (N,), device=dev)
+        _share_on_device(eng, torch, dev, stream, bit, n, t, tmp.data_ptr())
+        for p in range(n):
+            eng.d2d(fp.rbits + (p * m + j) * N * 32, tmp.data_ptr() + p * N * 32, N * 32, stream)
+    torch.cuda.synchronize()
+    ms = ev_time(fp.run, reps=3, warm=1)
+    res["cfg5_fpmul_16_parties"] = {"fpmuls_per_s": N / ms * 1e3, "ms": ms, "elements": N, "k": k, "f": m}
+    fp.close()
     return res
 
 

@@ -97,6 +97,7 @@ ShareErrorCode hbmpc_dev_alloc(hbmpc_ctx* ctx, size_t bytes, void** dptr_out);
 ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr);
 ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
+ShareErrorCode hbmpc_memcpy_d2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream); /* stream == NULL: the ctx's own stream */
 
 /* ==== a3: RobustShare::compute_shares / NonRobustShare::compute_shares ======================
@@ -150,6 +151,17 @@ ShareErrorCode hbmpc_dev_batch_recover_p0(hbmpc_ctx* ctx, const size_t* sender_i
                                           size_t G, size_t n, size_t d, size_t t, U256* secrets_out_dev,
                                           uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev,
                                           void* stream);
+
+/* Strided variant: sender i's values start at evals_dev + i * row_stride elements (row_stride >= G).
+ * With all n parties on one device the encode output of party p for recipient j is row (p, j) of a
+ * Y[n][n][G] array; recipient j decodes with evals_dev = &Y[0][j][0], row_stride = n * G -- the
+ * protocol's all-to-all (batch_recon.rs:173-183) becomes a layout choice, no data moves.
+ * p0_only != 0: out_dev is secrets[G] (ncoeffs_out_dev ignored), else coeffs[G][d+1]. */
+ShareErrorCode hbmpc_dev_batch_recover_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S,
+                                               const U256* evals_dev, size_t row_stride, size_t G, size_t n,
+                                               size_t d, size_t t, int p0_only, U256* out_dev,
+                                               uint32_t* ncoeffs_out_dev, uint8_t* status_out_dev,
+                                               hbmpc_recover_summary* summary_dev, void* stream);
 
 /* ==== a6: RobustShare::recover_secret (one polynomial) ======================================
  * replaces robust_interpolate.rs:94-157 (+ robust_interpolate_fnt :206-266, oec_decode :579-628,

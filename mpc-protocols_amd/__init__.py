@@ -6,5 +6,5 @@ hbmpc.py  ctypes binding used by tests/ and bench.py (plumbing; every call goes 
 The directory name carries a hyphen (it is the reference's repository name), so import it through
 `__graft_entry__.load_package()` which registers it as the module `mpc_protocols_amd`.
 """
-from . import hbmpc  # noqa: F401
+from . import hbmpc, pipelines  # noqa: F401
 from .hbmpc import Engine, HbmpcError, build, lib  # noqa: F401

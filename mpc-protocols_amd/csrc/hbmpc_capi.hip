@@ -162,6 +162,11 @@ extern "C" ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst, const void
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick(ctx, stream)));
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_memcpy_d2d(hbmpc_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick(ctx, stream)));
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream) {
     if (!ctx) return InvalidInput;
     HIP_TRY(ctx, hipStreamSynchronize(pick(ctx, stream)));

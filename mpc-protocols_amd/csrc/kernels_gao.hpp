@@ -29,8 +29,9 @@ struct GaoRound {
     uint32_t lb_off;     // LB[k][j] * R in device-constant form, [required][required]
 };
 struct GaoArgs {
-    const uint32_t* evals;     // [S][G] canonical
+    const uint32_t* evals;     // sender rows, canonical (row s at evals + rows[s] * row_stride * 8 words)
     size_t G;
+    size_t row_stride;
     const int* rows;           // [S] row of the s-th lowest sender id
     const uint32_t* alpha_s;   // [S] alpha of the s-th lowest sender id, device-constant form
     const GaoRound* rounds;    // [n_rounds]
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                             F::acc_fold(acc);
                             pending = 1;
                         }
-                        F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[j] * a.G + g) * 8), row + (size_t)j * NL);
+                        F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[j] * a.row_stride + g) * 8), row + (size_t)j * NL);
                         ++pending;
                     }
                     F::acc_fold(acc);
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                         acc = F::add(acc, lds_get<F>(fq + kx * NL));
                     }
                     const E val = F::cond_sub_r(F::mont(F::canon_loose(acc), a.one_plain));  // leave Montgomery form
-                    const E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.G + g) * 8);
+                    const E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.row_stride + g) * 8);
                     hit = F::eq_canon(val, ys) ? 1 : 0;
                 }
                 // block-wide sum via max of prefix counts is overkill: use LDS atomics

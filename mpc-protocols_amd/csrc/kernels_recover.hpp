@@ -20,8 +20,9 @@
 namespace hbmpc {
 
 struct RecoverArgs {
-    const uint32_t* evals;   // [S][G] canonical
+    const uint32_t* evals;   // sender rows, canonical; row s starts at evals + rows[s] * row_stride * 8 words
     size_t G;
+    size_t row_stride;       // elements between consecutive sender rows (G when the rows are dense)
     const int* rows;         // [needed] row (position in evals) of the s-th lowest sender id   (device)
     int needed;              // d + t + 1
     int m;                   // d + 1
@@ -104,11 +105,11 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     const size_t gg = live ? g : a.G - 1;
     E y[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8);
+    for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * 8);
     bool ok = true;
     for (int s = M; s < a.needed; ++s) {
         const E p = F::cond_sub_r(dot_row<F, M>(y, a.vm + (size_t)(s - M) * M * F::NL));
-        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.G + gg) * 8);
+        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * 8);
         ok = ok && F::eq_canon(p, ys);
     }
     flag_chunks<F>(live && !ok, g, a);
@@ -140,12 +141,12 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
                 F::acc_fold(acc);
                 pending = 1;  // the folded columns count as less than one term
             }
-            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8), row + i * F::NL);
+            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * 8), row + i * F::NL);
             ++pending;
         }
         F::acc_fold(acc);
         const E p = F::canon_loose(F::acc_reduce(acc));
-        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.G + gg) * 8);
+        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * 8);
         ok = ok && F::eq_canon(p, ys);
     }
     flag_chunks<F>(live && !ok, g, a);
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
                 F::acc_fold(acc);
                 pending = 1;
             }
-            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.G + gg) * 8), row + i * F::NL);
+            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * 8), row + i * F::NL);
             ++pending;
         }
         F::acc_fold(acc);

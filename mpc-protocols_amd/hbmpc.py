@@ -230,6 +230,14 @@ class Engine:
         rc = self.L.hbmpc_memcpy_d2h(self.ctx, _p(arr), C.c_void_p(dptr), C.c_size_t(arr.nbytes), C.c_void_p(stream))
         assert rc == 0, self.last_error()
 
+    def d2d(self, dst: int, src: int, nbytes: int, stream=0):
+        rc = self.L.hbmpc_memcpy_d2d(self.ctx, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), C.c_void_p(stream))
+        assert rc == 0, self.last_error()
+
+    def dev_fr_op(self, op, a_d, b_d, N, out_d, stream=0):
+        return self.L.hbmpc_dev_fr_op(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), C.c_void_p(a_d),
+                                      C.c_void_p(b_d), C.c_size_t(N), C.c_void_p(out_d), C.c_void_p(stream))
+
     def sync(self, stream=0):
         rc = self.L.hbmpc_stream_sync(self.ctx, C.c_void_p(stream))
         if rc != 0:
@@ -255,6 +263,15 @@ class Engine:
                                               C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(t),
                                               C.c_void_p(out_d), C.c_void_p(nco_d), C.c_void_p(status_d),
                                               C.c_void_p(summary_d), C.c_void_p(stream))
+
+    def dev_batch_recover_strided(self, sender_ids, evals_d, row_stride, G, n, d, t, out_d, p0=False, nco_d=0,
+                                  status_d=0, summary_d=0, stream=0):
+        ids = _sz(sender_ids)
+        return self.L.hbmpc_dev_batch_recover_strided(self.ctx, _p(ids), C.c_size_t(len(sender_ids)),
+                                                      C.c_void_p(evals_d), C.c_size_t(row_stride), C.c_size_t(G),
+                                                      C.c_size_t(n), C.c_size_t(d), C.c_size_t(t),
+                                                      C.c_int(1 if p0 else 0), C.c_void_p(out_d), C.c_void_p(nco_d),
+                                                      C.c_void_p(status_d), C.c_void_p(summary_d), C.c_void_p(stream))
 
     def dev_elem(self, name, ptrs, N, extra=(), stream=0):
         args = [self.ctx] + [C.c_void_p(p) for p in ptrs[: name_inputs(name)]] + [C.c_size_t(e) for e in extra] + \

@@ -1,0 +1,164 @@
+"""Device-resident replays of the reference's arithmetic pipelines for ALL n simulated parties on one
+GPU (how every reference test/bench runs: n parties in one process on FakeNetwork).  Host-side
+orchestration only -- every arithmetic step is an hbmpc_dev_* call; the parties' all-to-all is a
+layout choice (strided sender rows), nothing is copied between "parties".
+
+  triple_gen   TripleGenNode::init_batch + BatchReconNode (degree 2t) + try_finalize_triple_gen
+               triple_gen/triple_generation.rs:304-364,164-232; batch_recon/batch_recon.rs:144-185,332-481
+  fpmul        FPMulNode::init = Multiply (Beaver, RBC path) + TruncPrNode
+               fpmul/fpmul.rs:61-110, mul/multiplication.rs:417-426,57-139, fpmul/truncpr.rs:185-318
+"""
+from __future__ import annotations
+
+import numpy as np
+
+U = 32  # bytes per element
+
+
+class DeviceArena:
+    """bump allocator over one hbmpc_dev_alloc block (keeps the pipelines free of per-step mallocs)"""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.size, self.off = eng, nbytes, 0
+        self.base = eng.dev_alloc(nbytes)
+
+    def take(self, nbytes):
+        nbytes = (nbytes + 255) & ~255
+        assert self.off + nbytes <= self.size, "arena exhausted"
+        p = self.base + self.off
+        self.off += nbytes
+        return p
+
+    def free(self):
+        self.eng.dev_free(self.base)
+
+
+def _check(rc, eng, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} -> ShareErrorCode {rc}: {eng.last_error()}")
+
+
+def _summary_ok(eng, smd, what, stream=0):
+    s = np.zeros(4, dtype=np.uint32)
+    eng.d2h(s, smd, stream)
+    eng.sync(stream)
+    if s[1] != 0:
+        raise RuntimeError(f"{what}: {s[1]} chunks failed to decode (first {s[2]}, error {s[3]})")
+    return int(s[0])
+
+
+class TripleGen:
+    """n parties, threshold t, N triples (N a multiple of 2t+1).  Buffers are [party][N] canonical."""
+
+    def __init__(self, eng, n, t, N, stream=0):
+        assert N % (2 * t + 1) == 0
+        self.eng, self.n, self.t, self.N, self.stream = eng, n, t, N, stream
+        self.m = 2 * t + 1
+        self.G = N // self.m
+        G = self.G
+        self.arena = DeviceArena(eng, (5 * n * N + n * n * G + n * G + N) * U + (n + 2) * G + (1 << 14))
+        ar = self.arena
+        self.a, self.b, self.r2t, self.rt, self.c = (ar.take(n * N * U) for _ in range(5))
+        self.Y = ar.take(n * n * G * U)      # Y[p][j][g]: party p's evaluation for recipient j
+        self.Z = ar.take(n * G * U)          # Z[j][g]: recipient j's opened y_j (the broadcast RevealBatch)
+        self.opened = ar.take(N * U)         # [G][2t+1] == flat [N]
+        self.status = ar.take(G)
+        self.summ = ar.take(64)
+
+    def upload(self, a, b, r2t, rt):
+        for dst, src in ((self.a, a), (self.b, b), (self.r2t, r2t), (self.rt, rt)):
+            self.eng.h2d(dst, np.ascontiguousarray(src), self.stream)
+
+    def run(self, check=True):
+        e, n, t, N, G, m, s = self.eng, self.n, self.t, self.N, self.G, self.m, self.stream
+        d = 2 * t
+        ids = list(range(n))
+        # 1. every party: [ab - r]_2t = a_i * b_i - r2t_i   (triple_generation.rs:333-340), into c as scratch
+        for p in range(n):
+            o = p * N * U
+            _check(e.dev_elem("triple_local", [self.a + o, self.b + o, self.r2t + o, self.c + o], N, stream=s), e,
+                   "triple_local")
+        # 2. every party: Vandermonde-encode its chunks of 2t+1 -> y for each recipient (batch_recon.rs:157-165)
+        for p in range(n):
+            _check(e.dev_vandermonde_apply(self.c + p * N * U, G, n, d, self.Y + p * n * G * U, s), e, "encode")
+        # 3. EvalBatch arm: recipient j interpolates its y_j from the senders' evaluations (needs d+t+1 = 3t+1)
+        for j in range(n):
+            _check(e.dev_batch_recover_strided(ids, self.Y + j * G * U, n * G, G, n, d, t, self.Z + j * G * U, p0=True,
+                                               status_d=self.status, summary_d=self.summ, stream=s), e, "decode y_j")
+            if check:
+                _summary_ok(e, self.summ, f"EvalBatch decode for party {j}", s)
+        # 4. RevealBatch arm: everyone interpolates the 2t+1 opened values per chunk from the n broadcast y_j
+        _check(e.dev_batch_recover(ids, self.Z, G, n, d, t, self.opened, 0, self.status, self.summ, s), e, "decode open")
+        if check:
+            _summary_ok(e, self.summ, "RevealBatch decode", s)
+        # 5. every party: [c]_t = rt_i + opened   (triple_generation.rs:196-208)
+        for p in range(n):
+            o = p * N * U
+            _check(e.dev_elem("triple_finalize", [self.rt + o, self.opened, self.c + o], N, stream=s), e,
+                   "triple_finalize")
+
+    def download_c(self):
+        out = np.zeros((self.n, self.N, 4), dtype=np.uint64)
+        self.eng.d2h(out, self.c, self.stream)
+        self.eng.sync(self.stream)
+        return out
+
+    def close(self):
+        self.arena.free()
+
+
+class FpMul:
+    """Fixed-point multiplication of N element pairs for n parties: Beaver mul (a-x, b-y opened by direct
+    robust interpolation, i.e. the RBC path of Multiply::init for < t+1 leftovers that FPMulNode always
+    takes) followed by TruncPr with k-bit values and m fractional bits."""
+
+    def __init__(self, eng, n, t, N, k, m, stream=0):
+        self.eng, self.n, self.t, self.N, self.k, self.m, self.stream = eng, n, t, N, k, m, stream
+        self.arena = DeviceArena(eng, ((12 + m) * n * N + 4 * N) * U + 4 * N + (1 << 14))
+        ar = self.arena
+        (self.x, self.y, self.ta, self.tb, self.tc, self.rint, self.dsh, self.esh, self.z, self.rdash, self.osh,
+         self.out) = (ar.take(n * N * U) for _ in range(12))
+        self.rbits = ar.take(n * m * N * U)   # [party][bit][N]
+        self.dop, self.eop, self.cop = (ar.take(N * U) for _ in range(3))
+        self.status = ar.take(N)
+        self.summ = ar.take(64)
+
+    def upload(self, x, y, ta, tb, tc, rbits, rint):
+        for dst, src in ((self.x, x), (self.y, y), (self.ta, ta), (self.tb, tb), (self.tc, tc), (self.rbits, rbits),
+                         (self.rint, rint)):
+            self.eng.h2d(dst, np.ascontiguousarray(src), self.stream)
+
+    def _open(self, shares, out, what):
+        e, n, t, N, s = self.eng, self.n, self.t, self.N, self.stream
+        _check(e.dev_batch_recover(list(range(n)), shares, N, n, t, t, out, 0, self.status, self.summ, s, p0=True), e, what)
+        _summary_ok(e, self.summ, what, s)
+
+    def run(self):
+        e, n, N, k, m, s = self.eng, self.n, self.N, self.k, self.m, self.stream
+        o = lambda p: p * N * U  # noqa: E731
+        for p in range(n):   # multiplication.rs:417-426
+            _check(e.dev_elem("beaver_open_shares", [self.ta + o(p), self.tb + o(p), self.x + o(p), self.y + o(p),
+                                                     self.dsh + o(p), self.esh + o(p)], N, stream=s), e, "open shares")
+        self._open(self.dsh, self.dop, "open a-x")   # reconstruct_rbc: per-element recover_secret (:102-139)
+        self._open(self.esh, self.eop, "open b-y")
+        for p in range(n):   # finalize_mul (:57-100)
+            _check(e.dev_elem("beaver_finalize", [self.tc + o(p), self.x + o(p), self.y + o(p), self.dop, self.eop,
+                                                  self.z + o(p)], N, stream=s), e, "beaver_finalize")
+        for p in range(n):   # truncpr.rs:277-297
+            _check(e.dev_elem("truncpr_rdash", [self.rbits + p * m * N * U, self.rdash + o(p)], N, extra=(m,), stream=s),
+                   e, "rdash")
+            _check(e.dev_elem("truncpr_open_share", [self.z + o(p), self.rdash + o(p), self.rint + o(p), self.osh + o(p)],
+                              N, extra=(k, m), stream=s), e, "truncpr open share")
+        self._open(self.osh, self.cop, "open b+r")  # truncpr.rs:215
+        for p in range(n):   # truncpr.rs:216-220
+            _check(e.dev_elem("truncpr_finalize", [self.z + o(p), self.rdash + o(p), self.cop, self.out + o(p)], N,
+                              extra=(m,), stream=s), e, "truncpr finalize")
+
+    def download(self, which="out"):
+        out = np.zeros((self.n, self.N, 4), dtype=np.uint64)
+        self.eng.d2h(out, getattr(self, which), self.stream)
+        self.eng.sync(self.stream)
+        return out
+
+    def close(self):
+        self.arena.free()

@@ -1,0 +1,92 @@
+"""Device-resident replays of the reference pipelines (all n parties on one GPU) against the algebra:
+BASELINE config 4 (triple_gen) and config 5 (fpmul) shapes.  Every arithmetic step is an hbmpc_dev_*
+call; the oracle only generates inputs and checks outputs."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import cref as O
+from oracle import spec as S
+from tests import golden_util as GU
+
+pytestmark = pytest.mark.gpu
+R = S.R_MOD
+
+
+@pytest.fixture(scope="module")
+def pkg_eng():
+    pkg = load_package()
+    e = pkg.Engine(0)
+    yield pkg, e
+    e.close()
+
+
+def share_all(secrets_u256, n, d, seed):
+    """[n][N] degree-d sharings of N secrets (random higher coefficients), via the oracle"""
+    N = secrets_u256.shape[0]
+    co = O.fill_random(seed, N * (d + 1)).reshape(N, d + 1, 4)
+    co[:, 0] = secrets_u256
+    rc, sh = O.compute_shares(co, n, d)
+    assert rc == 0
+    return sh
+
+
+def open_all(shares, n, d, t):
+    rc, p0, st = O.batch_recover_p0(list(range(n)), shares, n, d, t)
+    assert rc == 0
+    return p0
+
+
+@pytest.mark.parametrize("n,t,groups", [(4, 1, 11), (7, 2, 40), (16, 5, 300)])
+def test_triple_gen_pipeline(pkg_eng, n, t, groups):
+    pkg, eng = pkg_eng
+    N = groups * (2 * t + 1)
+    a, b, r = O.fill_random(1, N), O.fill_random(2, N), O.fill_random(3, N)
+    sa, sb = share_all(a, n, t, 11), share_all(b, n, t, 12)
+    srt, sr2t = share_all(r, n, t, 13), share_all(r, n, 2 * t, 14)
+    tg = pkg.pipelines.TripleGen(eng, n, t, N)
+    tg.upload(sa, sb, sr2t, srt)
+    tg.run()
+    c = tg.download_c()
+    tg.close()
+    # [c]_t opens to a*b, and every party's share equals the reference algebra rt_i + (ab - r)
+    ab = O.fr_binop("mul", a, b)
+    assert GU.eq(open_all(c, n, t, t), ab)
+    opened = O.fr_binop("sub", ab, r)
+    for p in range(n):
+        assert GU.eq(c[p], O.triple_finalize(srt[p], opened)[1])
+
+
+@pytest.mark.parametrize("n,t,N,k,m", [(4, 1, 50, 16, 4), (7, 2, 64, 16, 4), (16, 5, 200, 32, 16)])
+def test_fpmul_pipeline(pkg_eng, n, t, N, k, m):
+    pkg, eng = pkg_eng
+    rng = np.random.default_rng(n)
+    half = (k - 2) // 2
+    xs = [int(v) for v in rng.integers(0, 1 << half, N)]
+    ys = [int(v) for v in rng.integers(0, 1 << half, N)]
+    x, y = O.ints_to_u256(xs), O.ints_to_u256(ys)
+    ta, tb = O.fill_random(21, N), O.fill_random(22, N)
+    tc = O.fr_binop("mul", ta, tb)
+    bits = rng.integers(0, 2, (m, N))
+    rints = [int(v) for v in rng.integers(0, 1 << 40, N)]
+    sx, sy = share_all(x, n, t, 31), share_all(y, n, t, 32)
+    sta, stb, stc = share_all(ta, n, t, 33), share_all(tb, n, t, 34), share_all(tc, n, t, 35)
+    srint = share_all(O.ints_to_u256(rints), n, t, 36)
+    sbits = np.stack([share_all(O.ints_to_u256([int(v) for v in bits[j]]), n, t, 40 + j) for j in range(m)], axis=1)  # [n][m][N]
+    fp = pkg.pipelines.FpMul(eng, n, t, N, k, m)
+    fp.upload(sx, sy, sta, stb, stc, np.ascontiguousarray(sbits), srint)
+    fp.run()
+    z = fp.download("z")
+    out = fp.download("out")
+    fp.close()
+    prod = [a * b for a, b in zip(xs, ys)]
+    assert O.u256_to_ints(open_all(z, n, t, t)) == prod                       # Beaver product
+    got = O.u256_to_ints(open_all(out, n, t, t))
+    for v, p in zip(got, prod):
+        assert v in (p >> m, (p >> m) + 1)                                    # probabilistic truncation
+    # exact identity of truncpr.rs:215-220 per party against the oracle's element-wise restatement
+    rdash_val = [sum(int(bits[j][i]) << j for j in range(m)) for i in range(N)]
+    c_open = O.ints_to_u256([(prod[i] + (1 << (k - 1)) + (rints[i] << m) + rdash_val[i]) % R for i in range(N)])
+    for p in range(n):
+        rd = O.truncpr_rdash(np.ascontiguousarray(sbits[p]), m)[1]
+        assert GU.eq(out[p], O.truncpr_finalize(z[p], rd, c_open, m)[1])
