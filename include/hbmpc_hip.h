@@ -225,6 +225,32 @@ ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U
 ShareErrorCode hbmpc_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out);
 ShareErrorCode hbmpc_dev_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out, void* stream);
 
+/* ==== wire codec: ark-serialize "compressed" payloads of the path ====
+ * Vec<F>  = u64-LE length, then 32-byte LE canonical elements (EvalBatch / RevealBatch payloads,
+ *           batch_recon.rs:173-176, 396-398; read back by common/utils.rs:3-21 deser_bounded_vec).
+ * Vec<RobustShare<F>> = u64-LE length, then 48-byte records value | id u64 | degree u64
+ *           (common/mod.rs:92-99; share_gen.rs:262-266).
+ * pack_fvec: rows_dev[n_rows] (row r at rows_dev + r*row_stride elements, G elements each) ->
+ *   payload r at payloads_dev + r*payload_stride_bytes (8-byte aligned, >= 8 + 32 G bytes).
+ *   After hbmpc_dev_vandermonde_apply, row j IS the EvalBatch payload body for recipient j.
+ * unpack_fvec: the inverse; status_dev[r] = 0, or InvalidInput (4) when the length prefix is not G or an
+ *   element is not canonical (ark returns SerializationError::InvalidData for both).
+ * pack_shares / unpack_shares: N values of one party (id, degree) <-> one Vec<RobustShare> payload;
+ *   status_dev[0] = 0 / 4 (length, non-canonical) / 3 (a record's id differs) / 2 (degree differs).
+ * validate_canonical: status_dev[0] = 4 if some element >= r (what Fr::from_bigint(..).unwrap() checks,
+ *   ffi/c_bindings/mod.rs:37-41). */
+ShareErrorCode hbmpc_dev_pack_fvec(hbmpc_ctx* ctx, const U256* rows_dev, size_t row_stride, size_t G, size_t n_rows,
+                                   void* payloads_dev, size_t payload_stride_bytes, void* stream);
+ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
+                                     size_t payload_bytes, size_t G, size_t n_rows, U256* rows_dev, size_t row_stride,
+                                     uint32_t* status_dev, void* stream);
+ShareErrorCode hbmpc_dev_pack_shares(hbmpc_ctx* ctx, const U256* values_dev, size_t N, size_t id, size_t degree,
+                                     void* payload_dev, void* stream);
+ShareErrorCode hbmpc_dev_unpack_shares(hbmpc_ctx* ctx, const void* payload_dev, size_t payload_bytes, size_t N, size_t id,
+                                       size_t degree, U256* values_dev, uint32_t* status_dev, void* stream);
+ShareErrorCode hbmpc_dev_validate_canonical(hbmpc_ctx* ctx, const U256* a_dev, size_t N, uint32_t* status_dev,
+                                            void* stream);
+
 /* ---- A/B aid: 0 = unsaturated 9x29-bit limbs (default, fast), 1 = saturated 8x32-bit limbs
  * (the straightforward formulation; same results, kept as a cross-check). */
 ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);

@@ -473,4 +473,71 @@ extern "C" ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, 
     });
 }
 
+// ---- wire codec ---------------------------------------------------
+extern "C" ShareErrorCode hbmpc_dev_pack_fvec(hbmpc_ctx* ctx, const U256* rows_dev, size_t row_stride, size_t G,
+                                              size_t n_rows, void* payloads_dev, size_t payload_stride_bytes,
+                                              void* stream) {
+    if (!ctx) return InvalidInput;
+    if (n_rows == 0) return ShareSuccess;
+    if (!rows_dev || !payloads_dev) return fail(ctx, InvalidInput, "null buffer");
+    if (payload_stride_bytes % 8 || payload_stride_bytes < 8 + 32 * G || ((uintptr_t)payloads_dev & 7) || row_stride < G)
+        return fail(ctx, InvalidInput, "payload stride must be 8-byte aligned and >= 8 + 32 G; row_stride >= G");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_pack_fvec((const uint64_t*)rows_dev, row_stride, G, n_rows, (uint64_t*)payloads_dev, payload_stride_bytes / 8,
+                     pick(ctx, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
+                                                size_t payload_bytes, size_t G, size_t n_rows, U256* rows_dev,
+                                                size_t row_stride, uint32_t* status_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (n_rows == 0) return ShareSuccess;
+    if (!rows_dev || !payloads_dev || !status_dev) return fail(ctx, InvalidInput, "null buffer");
+    if (payload_bytes < 8 || payload_bytes < 8 + 32 * G)  // common/utils.rs:7-9; a short read fails every element
+        return fail(ctx, InvalidInput, "payload shorter than its length prefix requires");
+    if (payload_stride_bytes % 8 || payload_stride_bytes < payload_bytes || ((uintptr_t)payloads_dev & 7) || row_stride < G)
+        return fail(ctx, InvalidInput, "payload stride must be 8-byte aligned and >= payload_bytes; row_stride >= G");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    HIP_TRY(ctx, hipMemsetAsync(status_dev, 0, n_rows * 4, s));
+    launch_unpack_fvec((const uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n_rows, (uint64_t*)rows_dev, row_stride,
+                       status_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_pack_shares(hbmpc_ctx* ctx, const U256* values_dev, size_t N, size_t id,
+                                                size_t degree, void* payload_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!payload_dev || (N && !values_dev) || ((uintptr_t)payload_dev & 7)) return fail(ctx, InvalidInput, "bad buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    launch_pack_shares((const uint64_t*)values_dev, N, id, degree, (uint64_t*)payload_dev, pick(ctx, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_unpack_shares(hbmpc_ctx* ctx, const void* payload_dev, size_t payload_bytes, size_t N,
+                                                  size_t id, size_t degree, U256* values_dev, uint32_t* status_dev,
+                                                  void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!payload_dev || !status_dev || (N && !values_dev) || ((uintptr_t)payload_dev & 7)) return fail(ctx, InvalidInput, "bad buffer");
+    if (payload_bytes < 8 + 48 * N) return fail(ctx, InvalidInput, "payload shorter than its length prefix requires");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    HIP_TRY(ctx, hipMemsetAsync(status_dev, 0, 4, s));
+    launch_unpack_shares((const uint64_t*)payload_dev, N, id, degree, (uint64_t*)values_dev, status_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_validate_canonical(hbmpc_ctx* ctx, const U256* a_dev, size_t N, uint32_t* status_dev,
+                                                       void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!status_dev || (N && !a_dev)) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    HIP_TRY(ctx, hipMemsetAsync(status_dev, 0, 4, s));
+    if (N) launch_validate_canonical((const uint64_t*)a_dev, N, status_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+
 #include "capi_recover.inc"

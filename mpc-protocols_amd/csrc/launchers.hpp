@@ -42,4 +42,14 @@ void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s);
 
+// wire codec (kernels_codec.hpp)
+void launch_pack_fvec(const uint64_t* rows, size_t row_stride, size_t G, size_t n_rows, uint64_t* payloads,
+                      size_t payload_stride_words, hipStream_t s);
+void launch_unpack_fvec(const uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, uint64_t* rows,
+                        size_t row_stride, uint32_t* status, hipStream_t s);
+void launch_pack_shares(const uint64_t* values, size_t N, uint64_t id, uint64_t degree, uint64_t* payload, hipStream_t s);
+void launch_unpack_shares(const uint64_t* payload, size_t N, uint64_t id, uint64_t degree, uint64_t* values,
+                          uint32_t* status, hipStream_t s);
+void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hipStream_t s);
+
 }  // namespace hbmpc

@@ -278,6 +278,32 @@ class Engine:
                [C.c_size_t(N)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
         return getattr(self.L, "hbmpc_dev_" + name)(*args)
 
+    # ---- wire codec ----
+    def dev_pack_fvec(self, rows_d, row_stride, G, n_rows, payloads_d, payload_stride_bytes, stream=0):
+        return self.L.hbmpc_dev_pack_fvec(self.ctx, C.c_void_p(rows_d), C.c_size_t(row_stride), C.c_size_t(G),
+                                          C.c_size_t(n_rows), C.c_void_p(payloads_d), C.c_size_t(payload_stride_bytes),
+                                          C.c_void_p(stream))
+
+    def dev_unpack_fvec(self, payloads_d, payload_stride_bytes, payload_bytes, G, n_rows, rows_d, row_stride, status_d,
+                        stream=0):
+        return self.L.hbmpc_dev_unpack_fvec(self.ctx, C.c_void_p(payloads_d), C.c_size_t(payload_stride_bytes),
+                                            C.c_size_t(payload_bytes), C.c_size_t(G), C.c_size_t(n_rows),
+                                            C.c_void_p(rows_d), C.c_size_t(row_stride), C.c_void_p(status_d),
+                                            C.c_void_p(stream))
+
+    def dev_pack_shares(self, values_d, N, id, degree, payload_d, stream=0):
+        return self.L.hbmpc_dev_pack_shares(self.ctx, C.c_void_p(values_d), C.c_size_t(N), C.c_size_t(id),
+                                            C.c_size_t(degree), C.c_void_p(payload_d), C.c_void_p(stream))
+
+    def dev_unpack_shares(self, payload_d, payload_bytes, N, id, degree, values_d, status_d, stream=0):
+        return self.L.hbmpc_dev_unpack_shares(self.ctx, C.c_void_p(payload_d), C.c_size_t(payload_bytes), C.c_size_t(N),
+                                              C.c_size_t(id), C.c_size_t(degree), C.c_void_p(values_d),
+                                              C.c_void_p(status_d), C.c_void_p(stream))
+
+    def dev_validate_canonical(self, a_d, N, status_d, stream=0):
+        return self.L.hbmpc_dev_validate_canonical(self.ctx, C.c_void_p(a_d), C.c_size_t(N), C.c_void_p(status_d),
+                                                   C.c_void_p(stream))
+
     def dev_modmul_ubench(self, out_d, threads, iters, stream=0):
         return self.L.hbmpc_dev_modmul_ubench(self.ctx, C.c_void_p(out_d), C.c_size_t(threads), C.c_uint32(iters),
                                               C.c_void_p(stream))

@@ -27,8 +27,9 @@ def _cpu_has_v3() -> bool:
 def build(force: bool = False) -> str:
     name = "libhbmpc_oracle_v3.so" if _cpu_has_v3() else "libhbmpc_oracle.so"
     so = os.path.join(_HERE, name)
-    src = os.path.join(_HERE, "hbmpc_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    # built explicitly by __graft_entry__.build() / `make -C oracle`; here only when missing (never on
+    # mtimes: several bench ranks may import this at once on a freshly copied tree)
+    if force or not os.path.exists(so):
         subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
     return so
 
