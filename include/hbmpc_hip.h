@@ -182,6 +182,17 @@ ShareErrorCode hbmpc_nonrobust_recover_secret(hbmpc_ctx* ctx, const size_t* ids,
                                               const U256* vals, size_t S, size_t n, U256* coeffs_out,
                                               size_t* ncoeffs_out, U256* secret_out);
 
+/* Batched form of the above for G columns that share the ids (the RanDouSha verifier reconstructs every
+ * column of a batch, ran_dou_sha/mod.rs:569-602): plain Lagrange through ALL S
+ * points.  coeffs_out[G][S] chunk-major (not trimmed), degree_out[G] = DensePolynomial::degree() of each
+ * (0 for the zero polynomial).  The caller applies the reference's checks (degree > share degree =>
+ * DegreeMismatch, shamir.rs:235; exact-degree and equal-secret tests of ran_dou_sha/mod.rs:586-589). */
+ShareErrorCode hbmpc_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals, size_t G,
+                                       size_t n, U256* coeffs_out, uint32_t* degree_out);
+ShareErrorCode hbmpc_dev_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals_dev,
+                                           size_t row_stride, size_t G, size_t n, U256* coeffs_out_dev,
+                                           uint32_t* degree_out_dev, void* stream);
+
 /* ==== a9/a11/a12/a13: element-wise share arithmetic of one party ============================
  * All arrays hold N elements of ONE party (same id, same degree: the id/degree checks of
  * common/mod.rs:167-300 are metadata and stay with the host mirror).  Host-pointer calls;

@@ -14,7 +14,8 @@
 //   value = sum l[i] * 2^(29 i), i < 9.   Montgomery radix R = 2^261.
 //   "normalised": l[i] < 2^29 (i < 8).    "loose": l[i] < 2^31 (sums of <= 4 normalised values).
 //   r = 2^254.86, so 2^261 = 70.5 r: REDC of a T-term dot product of values < r and constants < r
-//   is < (T/70.5 + 1) r  -- below 2r for every T <= 70 -- and lazily added values never overflow.
+//   is < (T/70.5 + 1) r  -- below 2r for every T <= 70 (the VALUE bound; the 64-bit COLUMN bound is
+//   tighter: the accumulator is carry-folded every 6 terms, see MAX_DOT_TERMS).
 //   -r^-1 mod 2^29 = 2^29 - 1 (r = 1 mod 2^32), so the Montgomery digit is m = (-acc) & MASK,
 //   and r's limb 0 is 1, so m*n0 is an add.
 //
@@ -33,7 +34,9 @@ namespace hbmpc {
 struct U29 {
     static constexpr int NL = 9;            // limbs per element / per constant
     static constexpr uint32_t MASK = 0x1fffffffu;
-    static constexpr int MAX_DOT_TERMS = 27;  // 9*T + 9 column products of < 2^58 must stay < 2^64
+    // A 64-bit column holds 2^64 / 2^58 = 64 products of normalised limbs.  A term adds up to 9 per column,
+    // the reduction up to 8 more (m * r) plus carries: 9 T + 9 <= 64  =>  T <= 6 terms between folds.
+    static constexpr int MAX_DOT_TERMS = 6;
 
     struct E {
         uint32_t l[9];
@@ -155,7 +158,7 @@ struct U29 {
 #pragma unroll
         for (int i = 0; i < 18; ++i) A.c[i] = 0;
     }
-    // a normalised, c normalised; at most MAX_DOT_TERMS terms between acc_zero/acc_fold
+    // a normalised, c normalised; at most MAX_DOT_TERMS (6) terms between acc_zero/acc_fold
     static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) {
 #pragma unroll
         for (int i = 0; i < 9; ++i)

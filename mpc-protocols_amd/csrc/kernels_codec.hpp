@@ -94,4 +94,21 @@ __global__ __launch_bounds__(256) void k_validate_canonical(const uint64_t* __re
     if (!is_canonical_u64x4(s[0], s[1], s[2], s[3])) atomicMax(status, 4u);
 }
 
+// degree_out[g] = DensePolynomial::degree() of coeffs[g][0..m): index of the highest non-zero coefficient,
+// 0 for the zero polynomial
+__global__ __launch_bounds__(256) void k_poly_degree(const uint64_t* __restrict__ coeffs, size_t G, int m,
+                                                     uint32_t* __restrict__ degree_out) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    int deg = 0;
+    for (int k = m - 1; k > 0; --k) {
+        const uint64_t* c = coeffs + (g * (size_t)m + k) * 4;
+        if ((c[0] | c[1] | c[2] | c[3]) != 0) {
+            deg = k;
+            break;
+        }
+    }
+    degree_out[g] = (uint32_t)deg;
+}
+
 }  // namespace hbmpc

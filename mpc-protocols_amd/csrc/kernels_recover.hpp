@@ -80,6 +80,7 @@ HB_DEV typename F::E dot_row(const typename F::E (&y)[M], const uint32_t* __rest
         ConstRegs<F> nxt = cur;
         if (i + 1 < M) nxt = load_uniform_const<F>(row + (i + 1) * F::NL);
         __builtin_amdgcn_sched_barrier(0);
+        if (i > 0 && i % F::MAX_DOT_TERMS == 0) F::acc_fold(acc);  // 64-bit column headroom: 6 terms per fold
         F::acc_mac_pinned(acc, y[i], cur.w);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
@@ -90,7 +91,6 @@ HB_DEV typename F::E dot_row(const typename F::E (&y)[M], const uint32_t* __rest
 template <class F, int M, bool P0_ONLY>
 __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     using E = typename F::E;
-    static_assert(M <= F::MAX_DOT_TERMS, "dot length");
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
     {
         const int vm_words = (a.needed - M) * M * F::NL, bc_words = (P0_ONLY ? 1 : M) * M * F::NL;

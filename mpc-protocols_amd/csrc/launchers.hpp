@@ -51,5 +51,6 @@ void launch_pack_shares(const uint64_t* values, size_t N, uint64_t id, uint64_t 
 void launch_unpack_shares(const uint64_t* payload, size_t N, uint64_t id, uint64_t degree, uint64_t* values,
                           uint32_t* status, hipStream_t s);
 void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hipStream_t s);
+void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, uint32_t* degree_out, hipStream_t s);
 
 }  // namespace hbmpc

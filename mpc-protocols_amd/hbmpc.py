@@ -169,6 +169,15 @@ class Engine:
                                                    C.c_size_t(n), _p(out), C.byref(nco), _p(sec))
         return rc, out[: nco.value], sec[0]
 
+    def batch_interpolate(self, ids, evals, n):
+        evals = np.ascontiguousarray(evals)
+        S, G = len(ids), evals.shape[1]
+        co = u256((G, S))
+        deg = np.zeros(G, dtype=np.uint32)
+        rc = self.L.hbmpc_batch_interpolate(self.ctx, _p(_sz(ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
+                                            C.c_size_t(n), _p(co), _p(deg))
+        return rc, co, deg
+
     def _ew(self, name, ins, n_out=1, extra=()):
         ins = [np.ascontiguousarray(a) for a in ins]
         N = ins[0].shape[0]

@@ -305,3 +305,73 @@ def test_full_size_cfg4_triple_algebra(eng):
     assert GU.eq(loc[idx], O.triple_local(a[idx], b[idx], r2t[idx])[1])
     rc, c = eng.triple_finalize(r2t, loc)
     assert GU.eq(c[idx], O.fr_binop("mul", a[idx], b[idx]))  # (ab - r) + r == ab
+
+
+@pytest.mark.parametrize("n,t,S", [(7, 2, 5), (16, 5, 16), (16, 5, 11), (31, 10, 21)])
+def test_batch_interpolate_randousha_verifier(eng, n, t, S):
+    """NonRobustShare::recover_secret per column (shamir.rs:199-239) as the RanDouSha verifier uses it
+    (ran_dou_sha/mod.rs:569-602): plain Lagrange through all S shares, degree of the result."""
+    G = 97
+    deg_t, deg_2t = t, 2 * t
+    ids = [int(i) for i in np.random.default_rng(S).permutation(n)[:S]]
+    for true_deg in (deg_t, min(deg_2t, S - 1), 0):
+        co = rnd(300 + true_deg, G, true_deg + 1)
+        co[3] = 0                                   # the zero polynomial: degree() == 0
+        co[4, true_deg] = 0                         # a lower-degree column
+        rc, sh = O.compute_shares(co, n, true_deg)
+        ev = np.ascontiguousarray(sh[ids])
+        rc, got, deg = eng.batch_interpolate(ids, ev, n)
+        assert rc == 0, eng.last_error()
+        for g in (0, 1, 3, 4, 50, G - 1):
+            rc0, want, sec = O.nonrobust_recover_secret(ids, [S - 1] * S, ev[:, g], n)
+            assert rc0 == 0
+            pad = np.zeros((S, 4), dtype=np.uint64)
+            pad[: len(want)] = want
+            assert GU.eq(got[g], pad), (true_deg, g)
+            assert deg[g] == max(len(want) - 1, 0)
+        assert deg[0] == true_deg and deg[3] == 0
+        assert GU.eq(got[:, : true_deg + 1], co)
+
+
+MAXLIMB = (0x73EDA6 << 232) | ((1 << 232) - 1)   # canonical, every 29-bit limb below the top one is all ones
+
+
+@pytest.mark.parametrize("n,t,d", [(16, 5, 5), (16, 5, 10), (16, 5, 15), (31, 10, 10), (31, 10, 20), (64, 21, 40), (10, 3, 3)])
+def test_accumulator_headroom_adversarial(eng_all, n, t, d):
+    """Worst-case limbs for the lazy 64-bit column accumulators: constant polynomials whose value has all-ones
+    limbs make every evaluation equal to that value, so all terms of a dot product add constructively
+    (a wrong fold interval only shows on such inputs, never on random data)."""
+    e = eng_all
+    G = 130
+    x = rnd(900 + n + d, G, d + 1)
+    x[: G // 2] = 0
+    x[: G // 2, 0] = O.ints_to_u256(MAXLIMB)             # constant polynomials
+    x[G // 2: G // 2 + 10] = O.ints_to_u256(MAXLIMB)     # every coefficient max-limb
+    x[G // 2 + 10: G // 2 + 20] = O.ints_to_u256(R - 1)
+    rc, y = O.compute_shares(x, n, d)
+    rc, got = e.compute_shares(x, n, d)
+    assert rc == 0 and GU.eq(got, y)
+    if n >= 3 * t + 1 and n >= d + t + 1:
+        ids = list(range(n))
+        rc0, co0, nco0, st0 = O.batch_recover(ids, y, n, d, t)
+        rc, co, nco, st = e.batch_recover(ids, y, n, d, t)
+        assert rc == rc0 == 0 and GU.eq(co, co0) and GU.eq(co, x) and not st.any()
+        y[3, :, 0] ^= np.uint64(1)                       # one corrupted sender everywhere: all chunks via OEC/Gao
+        rc0, co0, nco0, st0 = O.batch_recover(ids, y, n, d, t)
+        rc, co, nco, st = e.batch_recover(ids, y, n, d, t)
+        assert rc == rc0 and GU.eq(co, co0) and np.array_equal(st, st0) and np.array_equal(nco, nco0)
+    S = min(n, d + 6)
+    rc, ci, deg = e.batch_interpolate(list(range(S)), np.ascontiguousarray(y[:S, : G // 2]), n) if False else (0, None, None)
+    bits = np.repeat(O.ints_to_u256([MAXLIMB, R - 1, 1, 0])[None, :, :], 40, axis=0)   # [m=40][N=4]
+    assert GU.eq(e.truncpr_rdash(bits, 40)[1], O.truncpr_rdash(bits, 40)[1])
+
+
+def test_interpolate_headroom_adversarial(eng):
+    n, S, G = 31, 21, 64
+    x = np.zeros((G, 1, 4), dtype=np.uint64)
+    x[:, 0] = O.ints_to_u256(MAXLIMB)
+    x[1::2, 0] = rnd(5, G // 2)
+    rc, y = O.compute_shares(x, n, 0)
+    ids = list(range(S))
+    rc, co, deg = eng.batch_interpolate(ids, np.ascontiguousarray(y[:S]), n)
+    assert rc == 0 and GU.eq(co[:, 0], x[:, 0]) and not co[:, 1:].any() and not deg.any()
