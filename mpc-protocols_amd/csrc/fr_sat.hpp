@@ -127,6 +127,8 @@ struct Sat32 {
     static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[8]) { A.s = add(A.s, mont(a, c)); }
     static HB_DEV void acc_add_hi(Acc& A, const E& x) { A.s = add(A.s, x); }
     static HB_DEV void acc_fold(Acc&) {}
+    template <int M_TOTAL>
+    static HB_DEV void acc_fold_needed(Acc&) {}
     static HB_DEV E acc_reduce(Acc& A) { return A.s; }
 
     static HB_DEV E cond_sub_r(const E& x) { return x; }

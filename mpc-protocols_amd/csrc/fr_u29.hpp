@@ -204,6 +204,19 @@ struct U29 {
             A.c[i] &= MASK;
         }
     }
+    // Partial fold for a dot product of M_TOTAL terms: column k receives cnt_k = min(k, 16-k, 8) + 1 products per
+    // term, so only columns with cnt_k * M_TOTAL + 9 > 64 can ever overflow; the others are left alone.
+    template <int M_TOTAL>
+    static HB_DEV void acc_fold_needed(Acc& A) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+            const int cnt = (i < 8 ? i : (16 - i < 8 ? 16 - i : 8)) + 1;
+            if (cnt * M_TOTAL + 9 > 64) {
+                A.c[i + 1] += A.c[i] >> 29;
+                A.c[i] &= MASK;
+            }
+        }
+    }
     // Montgomery reduction of the 18 columns; result normalised, value < T/R + r
     static HB_DEV E acc_reduce(Acc& A) {
 #pragma unroll

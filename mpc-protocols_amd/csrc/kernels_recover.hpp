@@ -80,7 +80,7 @@ HB_DEV typename F::E dot_row(const typename F::E (&y)[M], const uint32_t* __rest
         ConstRegs<F> nxt = cur;
         if (i + 1 < M) nxt = load_uniform_const<F>(row + (i + 1) * F::NL);
         __builtin_amdgcn_sched_barrier(0);
-        if (i > 0 && i % F::MAX_DOT_TERMS == 0) F::acc_fold(acc);  // 64-bit column headroom: 6 terms per fold
+        if (i > 0 && i % F::MAX_DOT_TERMS == 0) F::template acc_fold_needed<M>(acc);  // 64-bit column headroom
         F::acc_mac_pinned(acc, y[i], cur.w);
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
