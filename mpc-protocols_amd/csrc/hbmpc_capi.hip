@@ -55,6 +55,12 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
         *out = it->second;
         return ShareSuccess;
     }
+    if (ctx->tables.size() >= 512) {  // bound the cache in a long-running node: drop everything (rare)
+        (void)hipDeviceSynchronize();    // tables may be in use by kernels on caller streams
+        for (auto& kv : ctx->tables) (void)hipFree(kv.second);
+        ctx->tables.clear();
+        ctx->layouts.clear();
+    }
     std::vector<uint32_t> host = build();
     if (host.empty()) host.push_back(0);
     uint32_t* dev = nullptr;

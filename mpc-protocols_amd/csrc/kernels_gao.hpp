@@ -32,7 +32,7 @@ struct GaoArgs {
     const uint32_t* evals;     // sender rows, canonical (row s at evals + rows[s] * row_stride * 8 words)
     size_t G;
     size_t row_stride;
-    const int* rows;           // [S] row of the s-th lowest sender id
+    const int* rows;           // [S] rows[s] = position of the s-th lowest sender id (device)
     const uint32_t* alpha_s;   // [S] alpha of the s-th lowest sender id, device-constant form
     const GaoRound* rounds;    // [n_rounds]
     int n_rounds;

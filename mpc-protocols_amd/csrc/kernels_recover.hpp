@@ -23,7 +23,7 @@ struct RecoverArgs {
     const uint32_t* evals;   // sender rows, canonical; row s starts at evals + rows[s] * row_stride * 8 words
     size_t G;
     size_t row_stride;       // elements between consecutive sender rows (G when the rows are dense)
-    const int* rows;         // [needed] row (position in evals) of the s-th lowest sender id   (device)
+    const int* rows;         // [S] rows[s] = position (in the caller's arrays) of the s-th lowest sender id (device)
     int needed;              // d + t + 1
     int m;                   // d + 1
     const uint32_t* vm;      // [(needed - m)][m] device-constant form
@@ -34,6 +34,20 @@ struct RecoverArgs {
     uint32_t* flagged;       // [G] compact list of failing chunks
     uint32_t* counters;      // [0] = number of flagged chunks
 };
+
+// The row permutation reaches the device through the arguments of a one-block kernel (no host buffer
+// whose lifetime an async copy would depend on, no cache entry per arrival order).
+struct RowsArg {
+    uint8_t r[256];
+};
+// Also the per-call initialisation: counters[0..4) = 0, summary = {0, 0, 0xffffffff, 0}.
+__global__ inline void k_store_rows(RowsArg a, int* __restrict__ dst, int S, uint32_t* __restrict__ counters,
+                                    uint32_t* __restrict__ summary) {
+    const int i = threadIdx.x;
+    if (i < S) dst[i] = a.r[i];
+    if (counters && i < 4) counters[i] = 0;  // [0] = flagged count ([4..8) may be the local summary)
+    if (summary && i < 4) summary[i] = i == 2 ? 0xffffffffu : 0u;
+}
 
 template <class F>
 HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
