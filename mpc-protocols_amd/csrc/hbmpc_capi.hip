@@ -27,6 +27,7 @@ struct hbmpc_ctx {
     std::mutex mu;                                 // serialises host-API calls and the table cache
     std::map<std::string, uint32_t*> tables;       // device-resident constant tables
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
+    std::map<hipStream_t, std::pair<void*, size_t>> scratch;  // per-stream scratch (calls on one stream are ordered)
     std::string err;
 };
 
@@ -68,6 +69,27 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
     HIP_TRY(ctx, hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice));
     ctx->tables[key] = dev;
     *out = dev;
+    return ShareSuccess;
+}
+// Per-stream scratch from plain hipMalloc.  NOT hipMallocAsync: data written to stream-ordered-pool memory by
+// one kernel was observed stale for workgroups of the NEXT kernel that run on other XCDs (their L2 kept the
+// value an earlier memset/kernel had left there), which silently dropped flagged chunks; ordinary hipMalloc
+// memory is coherent at kernel boundaries.  Calls on one stream are ordered, so they can share a buffer; it
+// only grows (after draining the stream).
+static ShareErrorCode get_scratch(hbmpc_ctx* ctx, hipStream_t s, size_t bytes, void** out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto& slot = ctx->scratch[s];
+    if (slot.second < bytes) {
+        if (slot.first) {
+            HIP_TRY(ctx, hipStreamSynchronize(s));
+            HIP_TRY(ctx, hipFree(slot.first));
+            slot = {nullptr, 0};
+        }
+        const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes + bytes / 2;
+        HIP_TRY(ctx, hipMalloc(&slot.first, want));
+        slot.second = want;
+    }
+    *out = slot.first;
     return ShareSuccess;
 }
 static std::string key(const char* kind, std::initializer_list<size_t> v, int impl) {
@@ -131,6 +153,7 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second);
+    for (auto& kv : ctx->scratch) (void)hipFree(kv.second.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

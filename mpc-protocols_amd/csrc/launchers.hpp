@@ -42,7 +42,6 @@ void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s);
 
-void launch_store_rows(const uint8_t* rows, int S, int* dst, uint32_t* counters, uint32_t* summary, hipStream_t s);
 // wire codec (kernels_codec.hpp)
 void launch_pack_fvec(const uint64_t* rows, size_t row_stride, size_t G, size_t n_rows, uint64_t* payloads,
                       size_t payload_stride_words, hipStream_t s);

@@ -21,9 +21,4 @@ void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint3
     if (impl == 0) hipLaunchKernelGGL((k_matvec<U29>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
     else hipLaunchKernelGGL((k_matvec<Sat32>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
 }
-void launch_store_rows(const uint8_t* rows, int S, int* dst, uint32_t* counters, uint32_t* summary, hipStream_t s) {
-    RowsArg a;
-    for (int i = 0; i < 256; ++i) a.r[i] = i < S ? rows[i] : 0;
-    hipLaunchKernelGGL(k_store_rows, dim3(1), dim3(256), 0, s, a, dst, S, counters, summary);
-}
 }

@@ -1,0 +1,25 @@
+"""Runs the C++ restatement of the reference's own unit tests (tests/cpp/test_reference_units.cpp) against
+the C++ host mirror include/hbmpc_shares.hpp -- the reference is compiled code, so the host side above the
+C ABI exists in C++ as well as in the ctypes mirror the other tests use."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "test_reference_units")
+
+
+def test_cpp_mirror_builds():
+    # host-only g++ compile + link against the in-tree library (no GPU needed)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    assert os.path.exists(BIN)
+
+
+@pytest.mark.gpu
+def test_reference_unit_tests_in_cpp():
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    p = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert "all reference unit tests passed" in p.stdout
