@@ -93,6 +93,9 @@ const char* hbmpc_last_error(const hbmpc_ctx* ctx);
 const char* hbmpc_version(void);
 
 /* ---- device memory / stream helpers (for hosts without their own HIP binding) ------------ */
+/* Device buffers passed to hbmpc_dev_* should come from hbmpc_dev_alloc / hipMalloc (what torch's caching
+ * allocator uses).  Stream-ordered pool memory (hipMallocAsync) is not recommended for buffers that one
+ * kernel writes and the next reads: see DESIGN.md section 4, "Scratch memory". */
 ShareErrorCode hbmpc_dev_alloc(hbmpc_ctx* ctx, size_t bytes, void** dptr_out);
 ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr);
 ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);

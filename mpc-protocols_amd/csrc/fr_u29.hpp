@@ -120,43 +120,74 @@ struct U29 {
         return r;
     }
 
+    // Montgomery digit of a column sum u that was pre-biased by MASK: ~u & MASK == (-(u - MASK)) & MASK, one
+    // v_bfi_b32 ((u & 0) | (~u & MASK)).
+    static HB_DEV uint32_t digit_of_biased(uint32_t u_lo) {
+        uint32_t m;
+        asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(m) : "v"(u_lo), "v"(MASK));
+        return m;
+    }
     // Montgomery product a*b/R (mod r) by product scanning.  a loose (limbs < 2^31), b normalised
     // (limbs < 2^29).  Result normalised, value < a*b/2^261 + r.
     // Column bound: 9*(2^31*2^29) + 8*2^58 + 2^29 + carry(2^35) < 1.27e19 < 2^64.
-    static HB_DEV E mont(const E& a, const uint32_t* __restrict__ b) {
-        uint32_t m[9];
-        uint64_t acc = 0;
+    // Digit step.  With t = column + carry the textbook step is m = (-t) & MASK; t += m; carry = t >> 29
+    // (five dependent instructions here).  t + m is t rounded UP to a multiple of 2^29, so the carry is
+    // (t + MASK) >> 29 whatever m is: every low column starts at MASK instead of 0 (free: it is the addend of
+    // its first mad), u = column + carry, carry' = u >> 29 and m = ~u & MASK -- three instructions, and the
+    // carry chain is two deep per digit.
+    // Plain C++ statement of the product (kept as the readable definition and as a cross-check of the asm
+    // version below, which is what the kernels run).
+    static HB_DEV E mont_cxx(const E& a, const uint32_t* __restrict__ b) {
+        uint64_t c[17];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) c[k] = k < 9 ? MASK : 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) c[j] += (uint64_t)a.l[0] * b[j];
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const uint64_t u = c[i] + carry;
+            const uint32_t m = digit_of_biased((uint32_t)u);
+            carry = u >> 29;
+            if (i < 8) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) c[i + 1 + j] += (uint64_t)a.l[i + 1] * b[j];
+            }
+#pragma unroll
+            for (int j = 1; j < 9; ++j) c[i + j] += (uint64_t)m * consts::U_MOD[j];
+        }
         E t;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-#pragma unroll
-            for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b[k - i];
-#pragma unroll
-            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * consts::U_MOD[k - i];
-            m[k] = (0u - (uint32_t)acc) & MASK;
-            acc += m[k];  // * n0 (= 1): low 29 bits are now zero
-            acc >>= 29;
-        }
-#pragma unroll
         for (int k = 9; k < 17; ++k) {
-#pragma unroll
-            for (int i = k - 8; i <= 8; ++i) {
-                acc += (uint64_t)a.l[i] * b[k - i];
-                acc += (uint64_t)m[i] * consts::U_MOD[k - i];
-            }
-            t.l[k - 9] = (uint32_t)acc & MASK;
-            acc >>= 29;
+            const uint64_t u = c[k] + carry;
+            t.l[k - 9] = (uint32_t)u & MASK;
+            carry = u >> 29;
         }
-        t.l[8] = (uint32_t)acc;
+        t.l[8] = (uint32_t)carry;
         return t;
+    }
+    // hipcc regroups the C++ version column by column (one long dependent mad chain per column) whatever
+    // the source order: the kernels use the hand-scheduled single-asm-block version (tools/gen_mont_asm.py).
+#include "fr_u29_mont_asm.inc"
+    static HB_DEV E mont(const E& a, const uint32_t* __restrict__ b) {
+        const uint32_t bb[9] = {b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8]};
+        return mont_asm_v(a, bb);
+    }
+    // c must be WAVE-UNIFORM (a table indexed by compile-time or loop constants): it is held in SGPRs
+    static HB_DEV E mulc_u(const E& a, const uint32_t* __restrict__ c) {
+        const uint32_t bb[9] = {c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]};
+        return mont_asm_s(a, bb);
     }
     static HB_DEV E mulc(const E& a, const uint32_t* __restrict__ c) { return mont(a, c); }
     static HB_DEV E mont(const E& a, const E& b) { return mont(a, b.l); }
 
     // ---- lazy dot products: acc += a*c (81 mads, no carries); one REDC at the end ------------
+    // the nine low columns start at MASK: the bias acc_reduce's digit step expects (see mont; carry-folding
+    // moves multiples of 2^29 from column i to column i+1 as units, which leaves every u of the reduction --
+    // and so every digit and carry -- unchanged)
     static HB_DEV void acc_zero(Acc& A) {
 #pragma unroll
-        for (int i = 0; i < 18; ++i) A.c[i] = 0;
+        for (int i = 0; i < 18; ++i) A.c[i] = i < 9 ? MASK : 0;
     }
     // a normalised, c normalised; at most MAX_DOT_TERMS (6) terms between acc_zero/acc_fold
     static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) {
@@ -221,8 +252,7 @@ struct U29 {
     static HB_DEV E acc_reduce(Acc& A) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const uint32_t m = (0u - (uint32_t)A.c[k]) & MASK;
-            A.c[k] += m;
+            const uint32_t m = digit_of_biased((uint32_t)A.c[k]);
             A.c[k + 1] += A.c[k] >> 29;
 #pragma unroll
             for (int j = 1; j < 9; ++j) A.c[k + j] += (uint64_t)m * consts::U_MOD[j];
