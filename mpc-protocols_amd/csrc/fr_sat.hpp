@@ -120,6 +120,7 @@ struct Sat32 {
         return csub(t, t[8]);
     }
     static HB_DEV E mulc(const E& a, const uint32_t* __restrict__ c) { return mont(a, c); }
+    static HB_DEV E mulc_u(const E& a, const uint32_t* __restrict__ c) { return mont(a, c); }  // uniform-constant form
     static HB_DEV E mont(const E& a, const E& b) { return mont(a, b.l); }
 
     static HB_DEV void acc_zero(Acc& A) { A.s = zero(); }

@@ -78,7 +78,7 @@ HB_DEV void fft_bfly(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ 
             t = tight ? X[iv] : F::canon_loose(X[iv]);
         } else {
             const E vin = bv.lbu > 4 ? F::normalize(X[iv]) : X[iv];
-            t = F::mulc(vin, tw + (k * (S / (2 * B))) * F::NL);
+            t = F::mulc_u(vin, tw + (k * (S / (2 * B))) * F::NL);
         }
         constexpr int tvb = k == 0 ? (tight ? bv.vb : 1) : 2;
         constexpr int K = sub_k(tvb);
@@ -108,6 +108,27 @@ HB_DEV void fft_stages(typename F::E (&X)[1 << LOG], const uint32_t* __restrict_
 template <class F, int LOG, int CNT, int LBU0, int VB0>
 HB_DEV void fft_pruned(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw) {
     if constexpr (LOG > 0) fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG>{});
+}
+// The same transform, but every output is handed to `sink(index, value)` as soon as its last butterfly is
+// done (the last stage produces X[i] and X[i + S/2] together).  The kernels canonicalise and store there, so
+// the stores of a tile are spread over the last stage's multiplies instead of bunched behind the arithmetic
+// -- the kernel's traffic alone needs ~150 us per 2^20 secrets (profiles/r01_store_pattern_ubench.txt), as
+// long as the arithmetic, so the two have to overlap.
+template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink, int... IDX>
+HB_DEV void fft_last_stage_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink,
+                                std::integer_sequence<int, IDX...>) {
+    ((fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 1, IDX>(X, tw), sink(std::integral_constant<int, IDX>{}, X[IDX]),
+      sink(std::integral_constant<int, IDX + (1 << (LOG - 1))>{}, X[IDX + (1 << (LOG - 1))])),
+     ...);
+}
+template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink>
+HB_DEV void fft_pruned_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink) {
+    if constexpr (LOG == 0) {
+        sink(std::integral_constant<int, 0>{}, X[0]);
+    } else {
+        if constexpr (LOG > 1) fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG - 1>{});
+        fft_last_stage_sink<F, LOG, CNT, LBU0, VB0>(X, tw, sink, std::make_integer_sequence<int, (1 << LOG) / 2>{});
+    }
 }
 template <int LOG, int CNT, int LBU0, int VB0>
 constexpr int fft_max_vb() {
@@ -177,8 +198,8 @@ HB_DEV void load_twisted_one(typename F::E (&X)[16], const uint32_t* __restrict_
                              const uint32_t* __restrict__ tr, int dp1, bool fold) {
     constexpr int k = bitrev_c(4, P);
     if constexpr (k < CNT) {
-        X[P] = F::mulc(F::load(row + k * 8), tr + k * F::NL);
-        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::mulc(F::load(row + (k + 16) * 8), tr + (k + 16) * F::NL));
+        X[P] = F::mulc_u(F::load(row + k * 8), tr + k * F::NL);
+        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::mulc_u(F::load(row + (k + 16) * 8), tr + (k + 16) * F::NL));
     }
 }
 template <class F, int CNT, int... P>
@@ -216,8 +237,10 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
     const uint32_t* row = lds + lane * tile_pitch_words(CNT);
     E X[S];
     load_plain<F, LOG, CNT>(X, row, CNT, false, std::make_integer_sequence<int, S>{});
-    fft_pruned<F, LOG, CNT, 1, 1>(X, tw);
-    store_all<F, S>(X, y, G, g, 0, 1, n, std::make_integer_sequence<int, S>{});
+    fft_pruned_sink<F, LOG, CNT, 1, 1>(X, tw, [&](auto idx, const E& v) {
+        constexpr int j = decltype(idx)::value;
+        if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, v);
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -244,14 +267,18 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
     {  // pass 0: no twist
         E X[16];
         load_plain<F, 4, CNT16>(X, row, dp1, FOLD, std::make_integer_sequence<int, 16>{});
-        fft_pruned<F, 4, CNT16, Q, Q>(X, tw16);
-        store_all<F, 16>(X, y, G, g, 0, P, n, std::make_integer_sequence<int, 16>{});
+        fft_pruned_sink<F, 4, CNT16, Q, Q>(X, tw16, [&](auto idx, const E& v) {
+            const int j = P * decltype(idx)::value;
+            if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, v);
+        });
     }
     for (int r = 1; r < P; ++r) {
         E X[16];
         load_twisted<F, CNT16>(X, row, twist + (size_t)r * dp1 * F::NL, dp1, FOLD, std::make_integer_sequence<int, 16>{});
-        fft_pruned<F, 4, CNT16, Q, 2 * Q>(X, tw16);
-        store_all<F, 16>(X, y, G, g, r, P, n, std::make_integer_sequence<int, 16>{});
+        fft_pruned_sink<F, 4, CNT16, Q, 2 * Q>(X, tw16, [&](auto idx, const E& v) {
+            const int j = r + P * decltype(idx)::value;
+            if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, v);
+        });
     }
 }
 
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict
         const uint32_t* a = alpha + (size_t)j * F::NL;
         E acc = F::load(row + (size_t)(dp1 - 1) * 8);
         for (int k = dp1 - 2; k >= 0; --k) {
-            acc = F::mulc(acc, a);  // < 2r, normalised
+            acc = F::mulc_u(acc, a);  // < 2r, normalised
             acc = F::add(acc, F::load(row + (size_t)k * 8));
             // value < 3r, limbs < 2^30: fine as the next mulc input
         }
