@@ -63,6 +63,23 @@ def cpu_baseline(n, d, sample):
                       f"{os.path.basename(cref.build())}", "seconds": round(dt, 2)}
 
 
+def cpu_baseline_threads(n, d, sample):
+    """the same restatement on every host core (the reference itself is single-threaded on this path; SURVEY 8(d)
+    asks for both).  ctypes releases the GIL during the C call."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import cref
+    cores = len(os.sched_getaffinity(0))
+    per = sample // cores
+    xs = [cref.fill_random(0xC0FFEE10 + i, per * (d + 1)).reshape(per, d + 1, 4) for i in range(cores)]
+    with ThreadPoolExecutor(cores) as ex:
+        t0 = time.perf_counter()
+        rcs = list(ex.map(lambda x: cref.compute_shares(x, n, d)[0], xs))
+        dt = time.perf_counter() - t0
+    assert not any(rcs)
+    return {"value": n * per * cores / dt, "unit": "share-evals/s", "cores": cores, "kind": "port",
+            "sample": f"compute_shares n={n} d={d} on {per} secrets per thread", "seconds": round(dt, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +190,7 @@ def main():
     if rank == 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(n, d, 1 << args.cpu_sample_log2)
         if not args.no_extra:
+            out["cpu_baseline_all_cores"] = cpu_baseline_threads(n, d, 1 << args.cpu_sample_log2)
             out["extra"] = extra_measurements(eng, torch, dev, stream, cref)
             # the second half of BASELINE.json's metric, for convenience at the top level
             out["recons_per_s"] = out["extra"]["cfg3_decode"]["recons_per_s"]
@@ -221,7 +239,26 @@ def extra_measurements(eng, torch, dev, stream, cref):
                                                summ.data_ptr(), stream, p0=True))
     res["cfg3_decode_p0"] = {"recons_per_s": G / ms * 1e3, "ms": ms,
                              "GBps_algorithmic": (d + t + 1 + 1) * 32 * G / ms / 1e6}
+    # the same decode with the t lowest-id senders corrupted in 1 % of the chunks (flag + OEC/Gao
+    # fallback on the device); results must still be the original polynomials
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC0FFEE04)
+    bad = torch.randperm(G, device=dev, generator=gen)[: G // 100]
+    y[:t, bad, 0] ^= 1  # flips the lowest bit of the value: still canonical
+    ms = ev_time(lambda: eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, co.data_ptr(), 0, st.data_ptr(),
+                                               summ.data_ptr(), stream), reps=5, warm=1)
+    torch.cuda.synchronize()
+    sm = summ.cpu().numpy().view(np.uint32)
+    assert bool((co == x).all()) and int(sm[0]) == G // 100 and int(sm[1]) == 0, sm
+    res["cfg3_decode_1pct_corrupted"] = {"recons_per_s": G / ms * 1e3, "ms": ms, "fallback_chunks": int(sm[0]),
+                                         "note": "t lowest-id senders corrupted in 1 % of chunks"}
     del x, y, co, sec
+    # achievable HBM rate of a plain device copy (report against the vendor peak AND this)
+    big = torch.empty((1 << 27,), dtype=torch.int64, device=dev)  # 1 GiB
+    dst = torch.empty_like(big)
+    ms = ev_time(lambda: dst.copy_(big), reps=5, warm=2)
+    res["device_copy_GBps"] = 2 * big.numel() * 8 / ms / 1e6
+    del big, dst
     # element-wise: triple_local on 2^22 elements (128 B/element)
     N = 1 << 22
     a = torch.from_numpy(cref.fill_random(1, N).view(np.int64)).to(dev)

@@ -65,8 +65,9 @@ typedef enum {
     HBMPC_OUT_OF_MEMORY = 101 /* device allocation failed */
 } ShareErrorCode;
 
-/* ffi/c_bindings/share/mod.rs:50-53 (FieldKind) */
-typedef enum { Bls12_381Fr = 0 } FieldKind;
+/* ffi/c_bindings/share/mod.rs:50-53 (FieldKind).  Goldilocks64 is this library's extension for the reference's small
+ * field (common/math/goldilocks.rs:4-13: p = 2^64 - 2^32 + 1, generator 7), SURVEY.md section 8(f) row 4. */
+typedef enum { Bls12_381Fr = 0, Goldilocks64 = 1 } FieldKind;
 
 /* per-chunk status written by the batch-recover calls */
 enum {
@@ -264,6 +265,73 @@ ShareErrorCode hbmpc_dev_unpack_shares(hbmpc_ctx* ctx, const void* payload_dev, 
                                        size_t degree, U256* values_dev, uint32_t* status_dev, void* stream);
 ShareErrorCode hbmpc_dev_validate_canonical(hbmpc_ctx* ctx, const U256* a_dev, size_t N, uint32_t* status_dev,
                                             void* stream);
+
+/* ==== Goldilocks variants ==========================================
+ * The reference instantiates the same generic code for GoldilocksField = Fp64<MontBackend<..>>
+ * (common/math/goldilocks.rs:4-13; RanShaNode / RanDouShaNode / TripleGenNode / RandBit over it,
+ * honeybadger/mod.rs:316-324).  These entry points are the hbmpc_* calls above with 8-byte canonical
+ * little-endian elements (what ark serialises for Fp64) instead of U256; same argument meaning, layouts,
+ * validation order and error codes.  They need a context created with FieldKind Goldilocks64; a context
+ * serves one field only (the other family returns TypeMismatch).  Non-canonical inputs (>= p) are the
+ * caller's error, as for Fr.  TruncPr and the wire codec are big-field-only in the reference and have no
+ * hbmpc_gl_ form. */
+ShareErrorCode hbmpc_gl_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs, size_t B, size_t n, size_t d,
+                                       uint64_t* shares_out);
+ShareErrorCode hbmpc_gl_dev_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs_dev, size_t B, size_t n, size_t d,
+                                           uint64_t* shares_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n, size_t d, uint64_t* y_out);
+ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
+                                              uint64_t* y_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, uint64_t* v_out);
+ShareErrorCode hbmpc_gl_batch_recover(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals, size_t G,
+                                      size_t n, size_t d, size_t t, uint64_t* coeffs_out, uint32_t* ncoeffs_out,
+                                      uint8_t* status_out);
+ShareErrorCode hbmpc_gl_batch_recover_p0(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals,
+                                         size_t G, size_t n, size_t d, size_t t, uint64_t* secrets_out, uint8_t* status_out);
+ShareErrorCode hbmpc_gl_dev_batch_recover(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals_dev,
+                                          size_t G, size_t n, size_t d, size_t t, uint64_t* coeffs_out_dev,
+                                          uint32_t* ncoeffs_out_dev, uint8_t* status_out_dev,
+                                          hbmpc_recover_summary* summary_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_batch_recover_p0(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals_dev,
+                                             size_t G, size_t n, size_t d, size_t t, uint64_t* secrets_out_dev,
+                                             uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_batch_recover_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S,
+                                                  const uint64_t* evals_dev, size_t row_stride, size_t G, size_t n, size_t d,
+                                                  size_t t, int p0_only, uint64_t* out_dev, uint32_t* ncoeffs_out_dev,
+                                                  uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
+ShareErrorCode hbmpc_gl_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals, size_t G,
+                                          size_t n, uint64_t* coeffs_out, uint32_t* degree_out);
+ShareErrorCode hbmpc_gl_dev_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals_dev,
+                                              size_t row_stride, size_t G, size_t n, uint64_t* coeffs_out_dev,
+                                              uint32_t* degree_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_recover_secret(hbmpc_ctx* ctx, const size_t* ids, const size_t* degrees, const uint64_t* vals,
+                                       size_t S, size_t n, size_t t, uint64_t* coeffs_out, size_t* ncoeffs_out,
+                                       uint64_t* secret_out);
+ShareErrorCode hbmpc_gl_gao_rs_decode(hbmpc_ctx* ctx, const uint64_t* received, size_t k, size_t n,
+                                      const size_t* erasure_positions, size_t n_erasures, uint64_t* coeffs_out,
+                                      size_t* ncoeffs_out);
+ShareErrorCode hbmpc_gl_nonrobust_recover_secret(hbmpc_ctx* ctx, const size_t* ids, const size_t* degrees,
+                                                 const uint64_t* vals, size_t S, size_t n, uint64_t* coeffs_out,
+                                                 size_t* ncoeffs_out, uint64_t* secret_out);
+ShareErrorCode hbmpc_gl_fr_op(hbmpc_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t N, uint64_t* out);
+ShareErrorCode hbmpc_gl_dev_fr_op(hbmpc_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t N, uint64_t* out,
+                                  void* stream);
+ShareErrorCode hbmpc_gl_triple_local(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, size_t N,
+                                     uint64_t* out);
+ShareErrorCode hbmpc_gl_dev_triple_local(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, size_t N,
+                                         uint64_t* out, void* stream);
+ShareErrorCode hbmpc_gl_triple_finalize(hbmpc_ctx* ctx, const uint64_t* rt, const uint64_t* opened, size_t N, uint64_t* c_out);
+ShareErrorCode hbmpc_gl_dev_triple_finalize(hbmpc_ctx* ctx, const uint64_t* rt, const uint64_t* opened, size_t N,
+                                            uint64_t* c_out, void* stream);
+ShareErrorCode hbmpc_gl_beaver_open_shares(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* x,
+                                           const uint64_t* y, size_t N, uint64_t* d_sh_out, uint64_t* e_sh_out);
+ShareErrorCode hbmpc_gl_dev_beaver_open_shares(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* x,
+                                               const uint64_t* y, size_t N, uint64_t* d_sh_out, uint64_t* e_sh_out,
+                                               void* stream);
+ShareErrorCode hbmpc_gl_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,
+                                        const uint64_t* d, const uint64_t* e, size_t N, uint64_t* z_out);
+ShareErrorCode hbmpc_gl_dev_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,
+                                            const uint64_t* d, const uint64_t* e, size_t N, uint64_t* z_out, void* stream);
 
 /* ---- A/B aid: 0 = unsaturated 9x29-bit limbs (default, fast), 1 = saturated 8x32-bit limbs
  * (the straightforward formulation; same results, kept as a cross-check). */

@@ -36,6 +36,7 @@ struct U29 {
     static constexpr uint32_t MASK = 0x1fffffffu;
     // A 64-bit column holds 2^64 / 2^58 = 64 products of normalised limbs.  A term adds up to 9 per column,
     // the reduction up to 8 more (m * r) plus carries: 9 T + 9 <= 64  =>  T <= 6 terms between folds.
+    static constexpr int EW = 8;  // u32 words per stored element
     static constexpr int MAX_DOT_TERMS = 6;
 
     struct E {

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/hbmpc_hip.h"
+#include "fr_gold.hpp"
 #include "kernels_elem.hpp"
 #include "launchers.hpp"
 #include "tables.hpp"
@@ -46,6 +47,12 @@ static ShareErrorCode fail(hbmpc_ctx* ctx, ShareErrorCode rc, const char* msg) {
     if (ctx) ctx->err = msg;
     return rc;
 }
+
+static bool is_gold(const hbmpc_ctx* ctx) { return ctx->impl == IMPL_GOLD; }
+static size_t ebytes(const hbmpc_ctx* ctx) { return impl_ebytes(ctx->impl); }
+// entry points are typed per field (U256* vs uint64_t*): a context only serves the field it was created for
+#define REQ_FR(ctx) do { if ((ctx) && is_gold(ctx)) return fail((ctx), TypeMismatch, "this context was created for Goldilocks: use the hbmpc_gl_* entry points"); } while (0)
+#define REQ_GL(ctx) do { if ((ctx) && !is_gold(ctx)) return fail((ctx), TypeMismatch, "this context was created for bls12-381 Fr: hbmpc_gl_* needs a Goldilocks64 context"); } while (0)
 
 // ---- table cache -------------------------------------------------------------------------------
 template <class Build>
@@ -109,6 +116,10 @@ static HFr rdev_value(int impl) {  // Rdev mod r as a field value: 2^256 (sat32)
 static ElemConsts elem_consts(int impl, const HFr* c0 = nullptr, const HFr* c1_plain = nullptr) {
     ElemConsts cs = {};
     std::vector<uint32_t> v;
+    if (impl == IMPL_GOLD) {  // no Montgomery form: mont(x, 1) = x
+        cs.r2[0] = 1;
+        return cs;
+    }
     put_const(v, rdev_value(impl), impl);
     for (int i = 0; i < impl_nl(impl); ++i) cs.r2[i] = v[i];
     if (c0) {
@@ -130,7 +141,7 @@ extern "C" const char* hbmpc_version(void) { return "hbmpc-hip 0.1 (gfx950)"; }
 extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out) {
     if (!ctx_out) return InvalidInput;
     *ctx_out = nullptr;
-    if (field_kind != Bls12_381Fr) return TypeMismatch;
+    if (field_kind != Bls12_381Fr && field_kind != Goldilocks64) return TypeMismatch;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
         g_err = "hbmpc_create: no HIP device " + std::to_string(device) + " (this library has no CPU path)";
@@ -145,6 +156,7 @@ extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_c
     }
     const char* env = getenv("HBMPC_FIELD_IMPL");
     if (env && std::string(env) == "sat32") ctx->impl = IMPL_SAT32;
+    if (field_kind == Goldilocks64) ctx->impl = IMPL_GOLD;
     *ctx_out = ctx;
     return ShareSuccess;
 }
@@ -160,6 +172,7 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
 extern "C" const char* hbmpc_last_error(const hbmpc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
+    REQ_FR(ctx);
     ctx->impl = impl;
     return ShareSuccess;
 }
@@ -230,13 +243,15 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
             return ShareSuccess;
     }
     const uint32_t* alpha;
-    ShareErrorCode rc = get_table(ctx, key("alpha", {n}, impl), [&] { return build_alpha(n, impl); }, &alpha);
+    ShareErrorCode rc = get_table(ctx, key("alpha", {n}, impl), [&] {
+        return impl == IMPL_GOLD ? build_alpha<HGl>(n, impl) : build_alpha<HFr>(n, impl);
+    }, &alpha);
     if (rc != ShareSuccess) return rc;
     launch_eval_generic(impl, x, G, (int)n, (int)dp1, alpha, y, s);
     return ShareSuccess;
 }
 
-static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d, U256* y, void* stream) {
+static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y, void* stream) {
     if (!ctx) return InvalidInput;
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");  // :59-64
     if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
@@ -253,10 +268,22 @@ static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n
 
 extern "C" ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B, size_t n, size_t d,
                                                    U256* shares_out, void* stream) {
+    REQ_FR(ctx);
     return eval_dev(ctx, coeffs, B, n, d, shares_out, stream);
 }
 extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d,
                                                       U256* y_out, void* stream) {
+    REQ_FR(ctx);
+    return eval_dev(ctx, x, G, n, d, y_out, stream);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs, size_t B, size_t n, size_t d,
+                                                      uint64_t* shares_out, void* stream) {
+    REQ_GL(ctx);
+    return eval_dev(ctx, coeffs, B, n, d, shares_out, stream);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n, size_t d,
+                                                         uint64_t* y_out, void* stream) {
+    REQ_GL(ctx);
     return eval_dev(ctx, x, G, n, d, y_out, stream);
 }
 
@@ -269,46 +296,70 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
-static ShareErrorCode eval_host(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d, U256* y) {
+static ShareErrorCode eval_host(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y) {
     if (!ctx) return InvalidInput;
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
     if (G == 0) return ShareSuccess;
     if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dx, dy;
-    HIP_TRY(ctx, dx.alloc(G * (d + 1) * 32));
-    HIP_TRY(ctx, dy.alloc(G * n * 32));
-    HIP_TRY(ctx, hipMemcpyAsync(dx.p, x, G * (d + 1) * 32, hipMemcpyHostToDevice, ctx->stream));
-    ShareErrorCode rc = eval_dev(ctx, (const U256*)dx.p, G, n, d, (U256*)dy.p, nullptr);
+    const size_t eb = ebytes(ctx);
+    HIP_TRY(ctx, dx.alloc(G * (d + 1) * eb));
+    HIP_TRY(ctx, dy.alloc(G * n * eb));
+    HIP_TRY(ctx, hipMemcpyAsync(dx.p, x, G * (d + 1) * eb, hipMemcpyHostToDevice, ctx->stream));
+    ShareErrorCode rc = eval_dev(ctx, dx.p, G, n, d, dy.p, nullptr);
     if (rc != ShareSuccess) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(y, dy.p, G * n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(y, dy.p, G * n * eb, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B, size_t n, size_t d,
                                                U256* shares_out) {
+    REQ_FR(ctx);
     return eval_host(ctx, coeffs, B, n, d, shares_out);
 }
 extern "C" ShareErrorCode hbmpc_vandermonde_apply(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d,
                                                   U256* y_out) {
+    REQ_FR(ctx);
     return eval_host(ctx, x, G, n, d, y_out);
 }
-extern "C" ShareErrorCode hbmpc_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, U256* v_out) {
-    // common/share/mod.rs:31-45.  A constant table (rows [1, alpha_j, ..., alpha_j^d]), built where
-    // every other table of this library is built: on the host.
+extern "C" ShareErrorCode hbmpc_gl_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs, size_t B, size_t n, size_t d,
+                                                  uint64_t* shares_out) {
+    REQ_GL(ctx);
+    return eval_host(ctx, coeffs, B, n, d, shares_out);
+}
+extern "C" ShareErrorCode hbmpc_gl_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n, size_t d,
+                                                     uint64_t* y_out) {
+    REQ_GL(ctx);
+    return eval_host(ctx, x, G, n, d, y_out);
+}
+// common/share/mod.rs:31-45.  A constant table (rows [1, alpha_j, ..., alpha_j^d]), built where every other
+// table of this library is built: on the host.
+template <class H>
+static ShareErrorCode make_vandermonde_t(hbmpc_ctx* ctx, size_t n, size_t d, void* v_out) {
     if (!ctx) return InvalidInput;
     if (n == 0) return ShareSuccess;
     if (!v_out) return fail(ctx, InvalidInput, "null buffer");
     if (domain_size(n) > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
-    const std::vector<HFr> el = domain_elements(n, n);
+    const std::vector<H> el = domain_elements<H>(n, n);
     for (size_t j = 0; j < n; ++j) {
-        HFr p = HFr::one();
+        H p = H::one();
         for (size_t k = 0; k <= d; ++k) {
-            p.to_canon(v_out[j * (d + 1) + k].data);
+            uint64_t c[4];
+            p.to_canon(c);
+            memcpy((uint8_t*)v_out + (j * (d + 1) + k) * H::EBYTES, c, H::EBYTES);
             p = p * el[j];
         }
     }
     return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, U256* v_out) {
+    REQ_FR(ctx);
+    return make_vandermonde_t<HFr>(ctx, n, d, v_out);
+}
+extern "C" ShareErrorCode hbmpc_gl_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, uint64_t* v_out) {
+    REQ_GL(ctx);
+    return make_vandermonde_t<HGl>(ctx, n, d, v_out);
 }
 
 // ---- element-wise ------------------------------------------------------------------------------
@@ -329,15 +380,29 @@ extern "C" ShareErrorCode hbmpc_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_
         HIP_TRY(ctx, hipGetLastError());                                                             \
     } while (0)
 
+#define BY_FIELD(KERNEL, ...)                                                                        \
+    do {                                                                                             \
+        if (ctx->impl == IMPL_U29)                                                                   \
+            hipLaunchKernelGGL((KERNEL<U29>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);             \
+        else if (ctx->impl == IMPL_SAT32)                                                            \
+            hipLaunchKernelGGL((KERNEL<Sat32>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);           \
+        else                                                                                         \
+            hipLaunchKernelGGL((KERNEL<Gold>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);            \
+        HIP_TRY(ctx, hipGetLastError());                                                             \
+    } while (0)
+
 #define W(p) ((const uint32_t*)(p))
 #define WO(p) ((uint32_t*)(p))
 
-extern "C" ShareErrorCode hbmpc_dev_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out,
-                                          void* stream) {
+static ShareErrorCode fr_op_any(hbmpc_ctx* ctx, int op, const void* a, const void* b, size_t N, void* out, void* stream) {
     ELEM_PROLOGUE
     if (op < 0 || op > 2) return fail(ctx, InvalidInput, "op must be 0 (add), 1 (sub) or 2 (mul)");
     const ElemConsts cs = elem_consts(ctx->impl);
-    if (ctx->impl == IMPL_U29) {
+    if (ctx->impl == IMPL_GOLD) {
+        if (op == 0) hipLaunchKernelGGL((k_binop<Gold, OP_ADD>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+        if (op == 1) hipLaunchKernelGGL((k_binop<Gold, OP_SUB>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+        if (op == 2) hipLaunchKernelGGL((k_binop<Gold, OP_MUL>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
+    } else if (ctx->impl == IMPL_U29) {
         if (op == 0) hipLaunchKernelGGL((k_binop<U29, OP_ADD>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
         if (op == 1) hipLaunchKernelGGL((k_binop<U29, OP_SUB>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
         if (op == 2) hipLaunchKernelGGL((k_binop<U29, OP_MUL>), dim3(grid), dim3(256), 0, s, W(a), W(b), N, cs, WO(out));
@@ -349,35 +414,63 @@ extern "C" ShareErrorCode hbmpc_dev_fr_op(hbmpc_ctx* ctx, int op, const U256* a,
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t,
-                                                 size_t N, U256* out, void* stream) {
+static ShareErrorCode triple_local_any(hbmpc_ctx* ctx, const void* a, const void* b, const void* r2t, size_t N, void* out,
+                                       void* stream) {
     ELEM_PROLOGUE
     const ElemConsts cs = elem_consts(ctx->impl);
-    BY_IMPL(k_triple_local, W(a), W(b), W(r2t), N, cs, WO(out));
+    BY_FIELD(k_triple_local, W(a), W(b), W(r2t), N, cs, WO(out));
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N,
-                                                    U256* c_out, void* stream) {
+static ShareErrorCode triple_finalize_any(hbmpc_ctx* ctx, const void* rt, const void* opened, size_t N, void* c_out,
+                                          void* stream) {
     ELEM_PROLOGUE
-    BY_IMPL(k_triple_finalize, W(rt), W(opened), N, WO(c_out));
+    BY_FIELD(k_triple_finalize, W(rt), W(opened), N, WO(c_out));
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x,
-                                                       const U256* y, size_t N, U256* d_sh, U256* e_sh,
-                                                       void* stream) {
+static ShareErrorCode beaver_open_any(hbmpc_ctx* ctx, const void* a, const void* b, const void* x, const void* y, size_t N,
+                                      void* d_sh, void* e_sh, void* stream) {
     ELEM_PROLOGUE
-    BY_IMPL(k_beaver_open, W(a), W(b), W(x), W(y), N, WO(d_sh), WO(e_sh));
+    BY_FIELD(k_beaver_open, W(a), W(b), W(x), W(y), N, WO(d_sh), WO(e_sh));
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y,
-                                                    const U256* d, const U256* e, size_t N, U256* z, void* stream) {
+static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const void* x, const void* y, const void* d,
+                                          const void* e, size_t N, void* z, void* stream) {
     ELEM_PROLOGUE
     const ElemConsts cs = elem_consts(ctx->impl);
-    BY_IMPL(k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z));
+    BY_FIELD(k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z));
     return ShareSuccess;
 }
+#define TYPED_PAIR(T, REQ, PFX)                                                                                          \
+    extern "C" ShareErrorCode PFX##dev_fr_op(hbmpc_ctx* ctx, int op, const T* a, const T* b, size_t N, T* out,           \
+                                             void* stream) {                                                             \
+        REQ(ctx);                                                                                                        \
+        return fr_op_any(ctx, op, a, b, N, out, stream);                                                                 \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_triple_local(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t, size_t N,      \
+                                                    T* out, void* stream) {                                              \
+        REQ(ctx);                                                                                                        \
+        return triple_local_any(ctx, a, b, r2t, N, out, stream);                                                         \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_triple_finalize(hbmpc_ctx* ctx, const T* rt, const T* opened, size_t N, T* c_out, \
+                                                       void* stream) {                                                   \
+        REQ(ctx);                                                                                                        \
+        return triple_finalize_any(ctx, rt, opened, N, c_out, stream);                                                   \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_beaver_open_shares(hbmpc_ctx* ctx, const T* a, const T* b, const T* x, const T* y, \
+                                                          size_t N, T* d_sh, T* e_sh, void* stream) {                    \
+        REQ(ctx);                                                                                                        \
+        return beaver_open_any(ctx, a, b, x, y, N, d_sh, e_sh, stream);                                                  \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_beaver_finalize(hbmpc_ctx* ctx, const T* c, const T* x, const T* y, const T* d,   \
+                                                       const T* e, size_t N, T* z, void* stream) {                       \
+        REQ(ctx);                                                                                                        \
+        return beaver_finalize_any(ctx, c, x, y, d, e, N, z, stream);                                                    \
+    }
+TYPED_PAIR(U256, REQ_FR, hbmpc_)
+TYPED_PAIR(uint64_t, REQ_GL, hbmpc_gl_)
 extern "C" ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N,
                                                   U256* r_dash, void* stream) {
+    REQ_FR(ctx);
     ELEM_PROLOGUE
     if (m > 4096) return fail(ctx, InvalidInput, "m beyond the supported range");
     const uint32_t* pow2;
@@ -390,6 +483,7 @@ extern "C" ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_
 extern "C" ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
                                                        const U256* r_int, size_t k, size_t m, size_t N, U256* open_out,
                                                        void* stream) {
+    REQ_FR(ctx);
     if (ctx && k == 0) return fail(ctx, InvalidInput, "k must be >= 1 (2^(k-1))");
     ELEM_PROLOGUE
     const HFr two = HFr::from_u64(2);
@@ -401,6 +495,7 @@ extern "C" ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U25
 extern "C" ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
                                                      const U256* c_open, size_t m, size_t N, U256* d_out,
                                                      void* stream) {
+    REQ_FR(ctx);
     // fpmul/mod.rs:381-406 indexes bytes[m/8] when m % 8 != 0: out of bounds (a panic) from m = 257 on
     if (ctx && m % 8 != 0 && m / 8 >= 32) return fail(ctx, InvalidInput, "m: bytes[m/8] out of bounds in the reference");
     ELEM_PROLOGUE
@@ -411,6 +506,7 @@ extern "C" ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256*
 }
 extern "C" ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev, size_t threads, uint32_t iters,
                                                   void* stream) {
+    REQ_FR(ctx);
     size_t N = threads;
     ELEM_PROLOGUE
     if (threads % 256) return fail(ctx, InvalidInput, "threads must be a multiple of 256");
@@ -421,84 +517,93 @@ extern "C" ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev,
 
 // host wrappers for the element-wise calls: n_in inputs of N elements (first input may be m*N), n_out outputs
 template <class Fn>
-static ShareErrorCode elem_host(hbmpc_ctx* ctx, std::initializer_list<std::pair<const U256*, size_t>> ins,
-                                std::initializer_list<std::pair<U256*, size_t>> outs, Fn fn) {
+static ShareErrorCode elem_host(hbmpc_ctx* ctx, std::initializer_list<std::pair<const void*, size_t>> ins,
+                                std::initializer_list<std::pair<void*, size_t>> outs, Fn fn) {
     if (!ctx) return InvalidInput;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t eb = ebytes(ctx);
     std::vector<DevBuf> bi(ins.size()), bo(outs.size());
-    std::vector<const U256*> pi;
-    std::vector<U256*> po;
+    std::vector<const void*> pi;
+    std::vector<void*> po;
     size_t k = 0;
     for (auto& in : ins) {
         if (in.second && !in.first) return fail(ctx, InvalidInput, "null buffer");
-        HIP_TRY(ctx, bi[k].alloc(in.second * 32));
-        HIP_TRY(ctx, hipMemcpyAsync(bi[k].p, in.first, in.second * 32, hipMemcpyHostToDevice, ctx->stream));
-        pi.push_back((const U256*)bi[k].p);
+        HIP_TRY(ctx, bi[k].alloc(in.second * eb));
+        HIP_TRY(ctx, hipMemcpyAsync(bi[k].p, in.first, in.second * eb, hipMemcpyHostToDevice, ctx->stream));
+        pi.push_back(bi[k].p);
         ++k;
     }
     k = 0;
     for (auto& o : outs) {
         if (o.second && !o.first) return fail(ctx, InvalidInput, "null buffer");
-        HIP_TRY(ctx, bo[k].alloc(o.second * 32));
-        po.push_back((U256*)bo[k].p);
+        HIP_TRY(ctx, bo[k].alloc(o.second * eb));
+        po.push_back(bo[k].p);
         ++k;
     }
     ShareErrorCode rc = fn(pi, po);
     if (rc != ShareSuccess) return rc;
     k = 0;
     for (auto& o : outs) {
-        HIP_TRY(ctx, hipMemcpyAsync(o.first, bo[k].p, o.second * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(o.first, bo[k].p, o.second * eb, hipMemcpyDeviceToHost, ctx->stream));
         ++k;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ShareSuccess;
 }
-typedef std::vector<const U256*> VI;
-typedef std::vector<U256*> VO;
+typedef std::vector<const void*> VI;
+typedef std::vector<void*> VO;
+#define CU(p) ((const U256*)(p))
+#define MU(p) ((U256*)(p))
 
-ShareErrorCode hbmpc_fr_op_host(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out) {
-    return elem_host(ctx, {{a, N}, {b, N}}, {{out, N}},
-                     [&](VI& i, VO& o) { return hbmpc_dev_fr_op(ctx, op, i[0], i[1], N, o[0], nullptr); });
-}
-extern "C" ShareErrorCode hbmpc_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out) {
-    return hbmpc_fr_op_host(ctx, op, a, b, N, out);
-}
-extern "C" ShareErrorCode hbmpc_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, size_t N,
-                                             U256* out) {
-    return elem_host(ctx, {{a, N}, {b, N}, {r2t, N}}, {{out, N}},
-                     [&](VI& i, VO& o) { return hbmpc_dev_triple_local(ctx, i[0], i[1], i[2], N, o[0], nullptr); });
-}
-extern "C" ShareErrorCode hbmpc_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N,
-                                                U256* c_out) {
-    return elem_host(ctx, {{rt, N}, {opened, N}}, {{c_out, N}},
-                     [&](VI& i, VO& o) { return hbmpc_dev_triple_finalize(ctx, i[0], i[1], N, o[0], nullptr); });
-}
-extern "C" ShareErrorCode hbmpc_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x,
-                                                   const U256* y, size_t N, U256* d_sh, U256* e_sh) {
-    return elem_host(ctx, {{a, N}, {b, N}, {x, N}, {y, N}}, {{d_sh, N}, {e_sh, N}}, [&](VI& i, VO& o) {
-        return hbmpc_dev_beaver_open_shares(ctx, i[0], i[1], i[2], i[3], N, o[0], o[1], nullptr);
-    });
-}
-extern "C" ShareErrorCode hbmpc_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y,
-                                                const U256* d, const U256* e, size_t N, U256* z) {
-    return elem_host(ctx, {{c, N}, {x, N}, {y, N}, {d, N}, {e, N}}, {{z, N}}, [&](VI& i, VO& o) {
-        return hbmpc_dev_beaver_finalize(ctx, i[0], i[1], i[2], i[3], i[4], N, o[0], nullptr);
-    });
-}
+#define TYPED_HOST(T, REQ, PFX)                                                                                          \
+    extern "C" ShareErrorCode PFX##fr_op(hbmpc_ctx* ctx, int op, const T* a, const T* b, size_t N, T* out) {             \
+        REQ(ctx);                                                                                                        \
+        return elem_host(ctx, {{a, N}, {b, N}}, {{out, N}},                                                              \
+                         [&](VI& i, VO& o) { return fr_op_any(ctx, op, i[0], i[1], N, o[0], nullptr); });                \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##triple_local(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t, size_t N, T* out) { \
+        REQ(ctx);                                                                                                        \
+        return elem_host(ctx, {{a, N}, {b, N}, {r2t, N}}, {{out, N}},                                                    \
+                         [&](VI& i, VO& o) { return triple_local_any(ctx, i[0], i[1], i[2], N, o[0], nullptr); });       \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##triple_finalize(hbmpc_ctx* ctx, const T* rt, const T* opened, size_t N, T* c_out) {   \
+        REQ(ctx);                                                                                                        \
+        return elem_host(ctx, {{rt, N}, {opened, N}}, {{c_out, N}},                                                      \
+                         [&](VI& i, VO& o) { return triple_finalize_any(ctx, i[0], i[1], N, o[0], nullptr); });          \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##beaver_open_shares(hbmpc_ctx* ctx, const T* a, const T* b, const T* x, const T* y,    \
+                                                      size_t N, T* d_sh, T* e_sh) {                                      \
+        REQ(ctx);                                                                                                        \
+        return elem_host(ctx, {{a, N}, {b, N}, {x, N}, {y, N}}, {{d_sh, N}, {e_sh, N}}, [&](VI& i, VO& o) {              \
+            return beaver_open_any(ctx, i[0], i[1], i[2], i[3], N, o[0], o[1], nullptr);                                 \
+        });                                                                                                              \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##beaver_finalize(hbmpc_ctx* ctx, const T* c, const T* x, const T* y, const T* d,       \
+                                                   const T* e, size_t N, T* z) {                                         \
+        REQ(ctx);                                                                                                        \
+        return elem_host(ctx, {{c, N}, {x, N}, {y, N}, {d, N}, {e, N}}, {{z, N}}, [&](VI& i, VO& o) {                    \
+            return beaver_finalize_any(ctx, i[0], i[1], i[2], i[3], i[4], N, o[0], nullptr);                             \
+        });                                                                                                              \
+    }
+TYPED_HOST(U256, REQ_FR, hbmpc_)
+TYPED_HOST(uint64_t, REQ_GL, hbmpc_gl_)
 extern "C" ShareErrorCode hbmpc_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, U256* r_dash) {
+    REQ_FR(ctx);
     return elem_host(ctx, {{r_bits, m * N}}, {{r_dash, N}},
-                     [&](VI& i, VO& o) { return hbmpc_dev_truncpr_rdash(ctx, i[0], m, N, o[0], nullptr); });
+                     [&](VI& i, VO& o) { return hbmpc_dev_truncpr_rdash(ctx, CU(i[0]), m, N, MU(o[0]), nullptr); });
 }
 extern "C" ShareErrorCode hbmpc_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
                                                    const U256* r_int, size_t k, size_t m, size_t N, U256* open_out) {
+    REQ_FR(ctx);
     return elem_host(ctx, {{a, N}, {r_dash, N}, {r_int, N}}, {{open_out, N}}, [&](VI& i, VO& o) {
-        return hbmpc_dev_truncpr_open_share(ctx, i[0], i[1], i[2], k, m, N, o[0], nullptr);
+        return hbmpc_dev_truncpr_open_share(ctx, CU(i[0]), CU(i[1]), CU(i[2]), k, m, N, MU(o[0]), nullptr);
     });
 }
 extern "C" ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
                                                  const U256* c_open, size_t m, size_t N, U256* d_out) {
+    REQ_FR(ctx);
     return elem_host(ctx, {{a, N}, {r_dash, N}, {c_open, N}}, {{d_out, N}}, [&](VI& i, VO& o) {
-        return hbmpc_dev_truncpr_finalize(ctx, i[0], i[1], i[2], m, N, o[0], nullptr);
+        return hbmpc_dev_truncpr_finalize(ctx, CU(i[0]), CU(i[1]), CU(i[2]), m, N, MU(o[0]), nullptr);
     });
 }
 
@@ -506,6 +611,7 @@ extern "C" ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, 
 extern "C" ShareErrorCode hbmpc_dev_pack_fvec(hbmpc_ctx* ctx, const U256* rows_dev, size_t row_stride, size_t G,
                                               size_t n_rows, void* payloads_dev, size_t payload_stride_bytes,
                                               void* stream) {
+    REQ_FR(ctx);
     if (!ctx) return InvalidInput;
     if (n_rows == 0) return ShareSuccess;
     if (!rows_dev || !payloads_dev) return fail(ctx, InvalidInput, "null buffer");
@@ -520,6 +626,7 @@ extern "C" ShareErrorCode hbmpc_dev_pack_fvec(hbmpc_ctx* ctx, const U256* rows_d
 extern "C" ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
                                                 size_t payload_bytes, size_t G, size_t n_rows, U256* rows_dev,
                                                 size_t row_stride, uint32_t* status_dev, void* stream) {
+    REQ_FR(ctx);
     if (!ctx) return InvalidInput;
     if (n_rows == 0) return ShareSuccess;
     if (!rows_dev || !payloads_dev || !status_dev) return fail(ctx, InvalidInput, "null buffer");
@@ -537,6 +644,7 @@ extern "C" ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payl
 }
 extern "C" ShareErrorCode hbmpc_dev_pack_shares(hbmpc_ctx* ctx, const U256* values_dev, size_t N, size_t id,
                                                 size_t degree, void* payload_dev, void* stream) {
+    REQ_FR(ctx);
     if (!ctx) return InvalidInput;
     if (!payload_dev || (N && !values_dev) || ((uintptr_t)payload_dev & 7)) return fail(ctx, InvalidInput, "bad buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -547,6 +655,7 @@ extern "C" ShareErrorCode hbmpc_dev_pack_shares(hbmpc_ctx* ctx, const U256* valu
 extern "C" ShareErrorCode hbmpc_dev_unpack_shares(hbmpc_ctx* ctx, const void* payload_dev, size_t payload_bytes, size_t N,
                                                   size_t id, size_t degree, U256* values_dev, uint32_t* status_dev,
                                                   void* stream) {
+    REQ_FR(ctx);
     if (!ctx) return InvalidInput;
     if (!payload_dev || !status_dev || (N && !values_dev) || ((uintptr_t)payload_dev & 7)) return fail(ctx, InvalidInput, "bad buffer");
     if (payload_bytes < 8 + 48 * N) return fail(ctx, InvalidInput, "payload shorter than its length prefix requires");
@@ -559,6 +668,7 @@ extern "C" ShareErrorCode hbmpc_dev_unpack_shares(hbmpc_ctx* ctx, const void* pa
 }
 extern "C" ShareErrorCode hbmpc_dev_validate_canonical(hbmpc_ctx* ctx, const U256* a_dev, size_t N, uint32_t* status_dev,
                                                        void* stream) {
+    REQ_FR(ctx);
     if (!ctx) return InvalidInput;
     if (!status_dev || (N && !a_dev)) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -17,6 +17,7 @@ struct HFr {  // Montgomery form, 4 x 64-bit limbs, radix 2^256
     static constexpr uint64_t MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL,
                                         0x73eda753299d7d48ULL};
     static constexpr uint64_t INV = 0xfffffffeffffffffULL;
+    static constexpr size_t EBYTES = 32;
     static HFr raw(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
         HFr r;
         r.l[0] = a, r.l[1] = b, r.l[2] = c, r.l[3] = d;
@@ -117,9 +118,21 @@ struct HFr {  // Montgomery form, 4 x 64-bit limbs, radix 2^256
         uint64_t ee[4] = {e, 0, 0, 0};
         return pow(ee);
     }
+    static void inv_exponent(uint64_t e[4]) { e[0] = MOD[0] - 2, e[1] = MOD[1], e[2] = MOD[2], e[3] = MOD[3]; }
     HFr inv() const {
-        uint64_t e[4] = {MOD[0] - 2, MOD[1], MOD[2], MOD[3]};
+        uint64_t e[4];
+        inv_exponent(e);
         return pow(e);
+    }
+    // 7^((r-1)/2^32): GENERATOR = 7, two-adicity 32
+    static HFr two_adic_root() {
+        const uint64_t rm1[4] = {MOD[0] - 1, MOD[1], MOD[2], MOD[3]};
+        uint64_t e[4];
+        e[0] = (rm1[0] >> 32) | (rm1[1] << 32);
+        e[1] = (rm1[1] >> 32) | (rm1[2] << 32);
+        e[2] = (rm1[2] >> 32) | (rm1[3] << 32);
+        e[3] = rm1[3] >> 32;
+        return from_u64(7).pow(e);
     }
     // ---- device constant formats ----
     // value v (this, Montgomery 2^256) -> limbs of v * Rdev mod r in the device representation
@@ -140,6 +153,46 @@ struct HFr {  // Montgomery form, 4 x 64-bit limbs, radix 2^256
             out[i] = (uint32_t)(v & 0x1fffffffu);
         }
     }
+};
+
+}  // namespace hbmpc
+
+namespace hbmpc {
+
+// Goldilocks p = 2^64 - 2^32 + 1 on the host (tables only, like HFr).  Plain canonical values: the device
+// representation has no Montgomery form.
+struct HGl {
+    uint64_t v;
+    typedef unsigned __int128 u128;
+    static constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
+    static constexpr size_t EBYTES = 8;
+    static HGl raw(uint64_t x) {
+        HGl r;
+        r.v = x;
+        return r;
+    }
+    static HGl zero() { return raw(0); }
+    static HGl one() { return raw(1); }
+    static HGl from_u64(uint64_t x) { return raw(x % P); }
+    bool is_zero() const { return v == 0; }
+    bool operator==(const HGl& o) const { return v == o.v; }
+    HGl operator+(const HGl& b) const { return raw((uint64_t)(((u128)v + b.v) % P)); }
+    HGl operator-(const HGl& b) const { return raw((uint64_t)(((u128)v + P - b.v) % P)); }
+    HGl neg() const { return zero() - *this; }
+    HGl operator*(const HGl& b) const { return raw((uint64_t)(((u128)v * b.v) % P)); }
+    HGl pow_u64(uint64_t e) const {
+        HGl acc = one(), base = *this;
+        for (; e; e >>= 1) {
+            if (e & 1) acc = acc * base;
+            base = base * base;
+        }
+        return acc;
+    }
+    HGl inv() const { return pow_u64(P - 2); }
+    void to_canon(uint64_t c[4]) const { c[0] = v, c[1] = c[2] = c[3] = 0; }
+    // 7^((p-1)/2^32): GENERATOR = 7, two-adicity 32 (common/math/goldilocks.rs:4-13)
+    static HGl two_adic_root() { return from_u64(7).pow_u64((P - 1) >> 32); }
+    static void inv_exponent(uint64_t e[4]) { e[0] = P - 2, e[1] = e[2] = e[3] = 0; }
 };
 
 }  // namespace hbmpc

@@ -96,14 +96,17 @@ __global__ __launch_bounds__(256) void k_validate_canonical(const uint64_t* __re
 
 // degree_out[g] = DensePolynomial::degree() of coeffs[g][0..m): index of the highest non-zero coefficient,
 // 0 for the zero polynomial
-__global__ __launch_bounds__(256) void k_poly_degree(const uint64_t* __restrict__ coeffs, size_t G, int m,
+// (ew64 = 64-bit words per element: 4 for Fr, 1 for Goldilocks)
+__global__ __launch_bounds__(256) void k_poly_degree(const uint64_t* __restrict__ coeffs, size_t G, int m, int ew64,
                                                      uint32_t* __restrict__ degree_out) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     int deg = 0;
     for (int k = m - 1; k > 0; --k) {
-        const uint64_t* c = coeffs + (g * (size_t)m + k) * 4;
-        if ((c[0] | c[1] | c[2] | c[3]) != 0) {
+        const uint64_t* c = coeffs + (g * (size_t)m + k) * ew64;
+        uint64_t any = 0;
+        for (int w = 0; w < ew64; ++w) any |= c[w];
+        if (any != 0) {
             deg = k;
             break;
         }

@@ -26,14 +26,14 @@ __global__ __launch_bounds__(256) void k_binop(const uint32_t* __restrict__ a, c
                                                size_t N, ElemConsts cs, uint32_t* __restrict__ out) {
     using E = typename F::E;
     HB_GID
-    const E x = F::load(a + i * 8), y = F::load(b + i * 8);
+    const E x = F::load(a + i * F::EW), y = F::load(b + i * F::EW);
     if constexpr (OP == OP_ADD) {
-        F::store_loose(out + i * 8, F::add(x, y));
+        F::store_loose(out + i * F::EW, F::add(x, y));
     } else if constexpr (OP == OP_SUB) {
-        F::store_loose(out + i * 8, F::template sub<2>(x, y));
+        F::store_loose(out + i * F::EW, F::template sub<2>(x, y));
     } else {
         const E xm = F::mulc(x, cs.r2);
-        F::store_lt2r(out + i * 8, F::mont(y, xm));
+        F::store_lt2r(out + i * F::EW, F::mont(y, xm));
     }
 }
 
@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void k_triple_local(const uint32_t* __restrict
                                                       uint32_t* __restrict__ out) {
     using E = typename F::E;
     HB_GID
-    const E am = F::mulc(F::load(a + i * 8), cs.r2);
-    const E p = F::mont(F::load(b + i * 8), am);  // a*b, < 2r
-    F::store_loose(out + i * 8, F::template sub<2>(p, F::load(r2t + i * 8)));
+    const E am = F::mulc(F::load(a + i * F::EW), cs.r2);
+    const E p = F::mont(F::load(b + i * F::EW), am);  // a*b, < 2r
+    F::store_loose(out + i * F::EW, F::template sub<2>(p, F::load(r2t + i * F::EW)));
 }
 // triple_generation.rs:196-208:  c = rt + opened
 template <class F>
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_triple_finalize(const uint32_t* __restr
                                                          const uint32_t* __restrict__ opened, size_t N,
                                                          uint32_t* __restrict__ out) {
     HB_GID
-    F::store_loose(out + i * 8, F::add(F::load(rt + i * 8), F::load(opened + i * 8)));
+    F::store_loose(out + i * F::EW, F::add(F::load(rt + i * F::EW), F::load(opened + i * F::EW)));
 }
 // mul/multiplication.rs:417-426:  d_sh = a - x, e_sh = b - y
 template <class F>
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void k_beaver_open(const uint32_t* __restrict_
                                                      size_t N, uint32_t* __restrict__ d_sh,
                                                      uint32_t* __restrict__ e_sh) {
     HB_GID
-    F::store_loose(d_sh + i * 8, F::template sub<2>(F::load(a + i * 8), F::load(x + i * 8)));
-    F::store_loose(e_sh + i * 8, F::template sub<2>(F::load(b + i * 8), F::load(y + i * 8)));
+    F::store_loose(d_sh + i * F::EW, F::template sub<2>(F::load(a + i * F::EW), F::load(x + i * F::EW)));
+    F::store_loose(e_sh + i * F::EW, F::template sub<2>(F::load(b + i * F::EW), F::load(y + i * F::EW)));
 }
 // multiplication.rs:57-100 finalize_mul:  z = c - d*e - d*y - e*x
 template <class F>
@@ -74,15 +74,15 @@ __global__ __launch_bounds__(256) void k_beaver_finalize(const uint32_t* __restr
                                                          uint32_t* __restrict__ z) {
     using E = typename F::E;
     HB_GID
-    const E dv = F::load(d + i * 8), ev = F::load(e + i * 8);
+    const E dv = F::load(d + i * F::EW), ev = F::load(e + i * F::EW);
     const E dm = F::mulc(dv, cs.r2), em = F::mulc(ev, cs.r2);  // Montgomery forms, normalised, < 2r
     const E de = F::mont(ev, dm);                              // d*e
-    const E dy = F::mont(F::load(y + i * 8), dm);              // d*[y]
-    const E ex = F::mont(F::load(x + i * 8), em);              // e*[x]
-    E acc = F::template sub<4>(F::load(c + i * 8), de);
+    const E dy = F::mont(F::load(y + i * F::EW), dm);              // d*[y]
+    const E ex = F::mont(F::load(x + i * F::EW), em);              // e*[x]
+    E acc = F::template sub<4>(F::load(c + i * F::EW), de);
     acc = F::template sub<4>(acc, dy);
     acc = F::template sub<4>(acc, ex);  // < 13 r, limbs < 2^29 + 3*2^30
-    F::store_loose(z + i * 8, acc);
+    F::store_loose(z + i * F::EW, acc);
 }
 // fpmul/truncpr.rs:277-283:  r_dash[i] = sum_{j<m} 2^j * r_bits[j][i];  pow2[j] = 2^j device-constant form
 template <class F>
@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void k_truncpr_rdash(const uint32_t* __restric
             F::acc_fold(acc);
             pending = 1;
         }
-        F::acc_mac(acc, F::load(r_bits + ((size_t)j * N + i) * 8), pow2 + (size_t)j * F::NL);
+        F::acc_mac(acc, F::load(r_bits + ((size_t)j * N + i) * F::EW), pow2 + (size_t)j * F::NL);
         ++pending;
     }
     F::acc_fold(acc);
     const E r = F::acc_reduce(acc);
-    F::store_loose(out + i * 8, r);
+    F::store_loose(out + i * F::EW, r);
 }
 // truncpr.rs:275,294-297:  open = (a + 2^(k-1)) + (2^m * r_int + r_dash);  cs.c0 = 2^m (const form), cs.c1 = 2^(k-1) limbs
 template <class F>
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256) void k_truncpr_open(const uint32_t* __restrict
                                                       uint32_t* __restrict__ out) {
     using E = typename F::E;
     HB_GID
-    E acc = F::add(F::load(a + i * 8), F::load_const(cs.c1));
-    acc = F::add(acc, F::mulc(F::load(r_int + i * 8), cs.c0));
-    acc = F::add(acc, F::load(r_dash + i * 8));
-    F::store_loose(out + i * 8, acc);
+    E acc = F::add(F::load(a + i * F::EW), F::load_const(cs.c1));
+    acc = F::add(acc, F::mulc(F::load(r_int + i * F::EW), cs.c0));
+    acc = F::add(acc, F::load(r_dash + i * F::EW));
+    F::store_loose(out + i * F::EW, acc);
 }
 // truncpr.rs:215-220 + fpmul/mod.rs:381-406:  d = (a - ((c mod 2^m) - r_dash)) * (2^m)^-1;  cs.c0 = (2^m)^-1
 template <class F>
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void k_truncpr_finalize(const uint32_t* __rest
     using E = typename F::E;
     HB_GID
     // low m bits of the canonical integer: mask the 8 little-endian words
-    const uint4 lo = *reinterpret_cast<const uint4*>(c_open + i * 8);
-    const uint4 hi = *reinterpret_cast<const uint4*>(c_open + i * 8 + 4);
+    const uint4 lo = *reinterpret_cast<const uint4*>(c_open + i * F::EW);
+    const uint4 hi = *reinterpret_cast<const uint4*>(c_open + i * F::EW + 4);
     uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -146,9 +146,9 @@ __global__ __launch_bounds__(256) void k_truncpr_finalize(const uint32_t* __rest
     } else {
         cm = F::load(tmp);
     }
-    E t = F::template sub<2>(F::load(r_dash + i * 8), cm);   // r_dash - c_mod  (= -(c_mod - r_dash)), + 2r
-    t = F::add(t, F::load(a + i * 8));                        // a - a'
-    F::store_lt2r(out + i * 8, F::mulc(t, cs.c0));
+    E t = F::template sub<2>(F::load(r_dash + i * F::EW), cm);   // r_dash - c_mod  (= -(c_mod - r_dash)), + 2r
+    t = F::add(t, F::load(a + i * F::EW));                        // a - a'
+    F::store_lt2r(out + i * F::EW, F::mulc(t, cs.c0));
 }
 
 // register-resident Montgomery-multiply chain: the integer-ALU ceiling of the field implementation
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_modmul_ubench(uint32_t* __restrict__ ou
         x = F::mont(x, y);
         y = F::mont(y, x);
     }
-    F::store_lt2r(out + i * 8, F::mont(x, y));
+    F::store_lt2r(out + i * F::EW, F::mont(x, y));
 }
 
 }  // namespace hbmpc

@@ -294,16 +294,16 @@ __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict
     using E = typename F::E;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
-    const uint32_t* row = x + g * (size_t)dp1 * 8;
+    const uint32_t* row = x + g * (size_t)dp1 * F::EW;
     for (int j = 0; j < n; ++j) {
         const uint32_t* a = alpha + (size_t)j * F::NL;
-        E acc = F::load(row + (size_t)(dp1 - 1) * 8);
+        E acc = F::load(row + (size_t)(dp1 - 1) * F::EW);
         for (int k = dp1 - 2; k >= 0; --k) {
             acc = F::mulc_u(acc, a);  // < 2r, normalised
-            acc = F::add(acc, F::load(row + (size_t)k * 8));
+            acc = F::add(acc, F::load(row + (size_t)k * F::EW));
             // value < 3r, limbs < 2^30: fine as the next mulc input
         }
-        F::store_loose(y + ((size_t)j * G + g) * 8, acc);
+        F::store_loose(y + ((size_t)j * G + g) * F::EW, acc);
     }
 }
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                             F::acc_fold(acc);
                             pending = 1;
                         }
-                        F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[j] * a.row_stride + g) * 8), row + (size_t)j * NL);
+                        F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[j] * a.row_stride + g) * F::EW), row + (size_t)j * NL);
                         ++pending;
                     }
                     F::acc_fold(acc);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                         acc = F::add(acc, lds_get<F>(fq + kx * NL));
                     }
                     const E val = F::cond_sub_r(F::mont(F::canon_loose(acc), a.one_plain));  // leave Montgomery form
-                    const E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.row_stride + g) * 8);
+                    const E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.row_stride + g) * F::EW);
                     hit = F::eq_canon(val, ys) ? 1 : 0;
                 }
                 // block-wide sum via max of prefix counts is overkill: use LDS atomics
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 if (tid < a.out_width) {
                     E c = F::zero();
                     if (tid <= df) c = F::cond_sub_r(F::mont(lds_get<F>(fq + tid * NL), a.one_plain));
-                    F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * 8, c);
+                    F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * F::EW, c);
                 }
                 out_len = df + 1;
                 result = ShareSuccess;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             }
         }
         if (result != ShareSuccess && tid < a.out_width) {
-            F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * 8, F::zero());
+            F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * F::EW, F::zero());
         }
         if (tid == 0) {
             if (a.ncoeffs) a.ncoeffs[g] = result == ShareSuccess ? (uint32_t)out_len : 0u;
@@ -302,11 +302,11 @@ __global__ __launch_bounds__(256) void k_matvec(const uint32_t* __restrict__ lb,
             F::acc_fold(acc);
             pending = 1;
         }
-        F::acc_mac(acc, F::load(y + (size_t)j * 8), lb + ((size_t)k * S + j) * F::NL);
+        F::acc_mac(acc, F::load(y + (size_t)j * F::EW), lb + ((size_t)k * S + j) * F::NL);
         ++pending;
     }
     F::acc_fold(acc);
-    F::store_loose(out + (size_t)k * 8, F::acc_reduce(acc));
+    F::store_loose(out + (size_t)k * F::EW, F::acc_reduce(acc));
 }
 
 }  // namespace hbmpc

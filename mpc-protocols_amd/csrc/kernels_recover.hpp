@@ -141,12 +141,12 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
                 F::acc_fold(acc);
                 pending = 1;  // the folded columns count as less than one term
             }
-            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * 8), row + i * F::NL);
+            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * F::EW), row + i * F::NL);
             ++pending;
         }
         F::acc_fold(acc);
         const E p = F::canon_loose(F::acc_reduce(acc));
-        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * 8);
+        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * F::EW);
         ok = ok && F::eq_canon(p, ys);
     }
     flag_chunks<F>(live && !ok, g, a);
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
                 F::acc_fold(acc);
                 pending = 1;
             }
-            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * 8), row + i * F::NL);
+            F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * F::EW), row + i * F::NL);
             ++pending;
         }
         F::acc_fold(acc);
-        F::store_loose(a.out + (g * (size_t)OW + k) * 8, F::acc_reduce(acc));
+        F::store_loose(a.out + (g * (size_t)OW + k) * F::EW, F::acc_reduce(acc));
     }
     if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
 }

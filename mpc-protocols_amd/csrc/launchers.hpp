@@ -28,7 +28,7 @@ bool launch_fftP_d(int dp1, const uint32_t* x, size_t G, int n, int P, const uin
                    uint32_t* y, hipStream_t s);
 bool launch_fftP_fold(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
                       uint32_t* y, hipStream_t s);
-// generic Horner evaluation (impl: 0 = U29, 1 = Sat32)
+// generic Horner evaluation (impl: 0 = U29, 1 = Sat32, 2 = Goldilocks)
 void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y,
                          hipStream_t s);
 // batch recover, U29, register-resident m <= 16
@@ -40,6 +40,7 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
 // OEC / Gao, matvec
 void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
+void launch_gao_gold(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s);
 
 // wire codec (kernels_codec.hpp)
@@ -51,6 +52,6 @@ void launch_pack_shares(const uint64_t* values, size_t N, uint64_t id, uint64_t 
 void launch_unpack_shares(const uint64_t* payload, size_t N, uint64_t id, uint64_t degree, uint64_t* values,
                           uint32_t* status, hipStream_t s);
 void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hipStream_t s);
-void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, uint32_t* degree_out, hipStream_t s);
+void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s);
 
 }  // namespace hbmpc

@@ -10,8 +10,9 @@
 
 namespace hbmpc {
 
-enum FieldImpl { IMPL_U29 = 0, IMPL_SAT32 = 1 };
-inline int impl_nl(int impl) { return impl == IMPL_U29 ? 9 : 8; }
+enum FieldImpl { IMPL_U29 = 0, IMPL_SAT32 = 1, IMPL_GOLD = 2 };
+inline int impl_nl(int impl) { return impl == IMPL_U29 ? 9 : impl == IMPL_SAT32 ? 8 : 2; }
+inline size_t impl_ebytes(int impl) { return impl == IMPL_GOLD ? 8 : 32; }  // bytes per stored element
 
 inline void put_const(std::vector<uint32_t>& out, const HFr& v, int impl) {
     uint32_t tmp[9];
@@ -42,6 +43,12 @@ inline void put_plain(std::vector<uint32_t>& out, const HFr& v, int impl) {
     }
 }
 
+inline void put_const(std::vector<uint32_t>& out, const HGl& v, int) {
+    out.push_back((uint32_t)v.v);
+    out.push_back((uint32_t)(v.v >> 32));
+}
+inline void put_plain(std::vector<uint32_t>& out, const HGl& v, int impl) { put_const(out, v, impl); }
+
 inline size_t domain_size(size_t n) {
     size_t s = 1;
     while (s < n) s <<= 1;
@@ -53,25 +60,21 @@ inline int ilog2(size_t s) {
     return l;
 }
 // omega_size = 7^((r-1)/2^32) ^ (2^32/size)   (common/mod.rs:51-68 -> GeneralEvaluationDomain::new)
-inline bool domain_omega(size_t size, HFr* w) {
+template <class H>
+inline bool domain_omega(size_t size, H* w) {
     const int lg = ilog2(size);
     if (lg > 32) return false;
-    const uint64_t rm1[4] = {HFr::MOD[0] - 1, HFr::MOD[1], HFr::MOD[2], HFr::MOD[3]};
-    uint64_t e[4];
-    e[0] = (rm1[0] >> 32) | (rm1[1] << 32);
-    e[1] = (rm1[1] >> 32) | (rm1[2] << 32);
-    e[2] = (rm1[2] >> 32) | (rm1[3] << 32);
-    e[3] = rm1[3] >> 32;
-    HFr root = HFr::from_u64(7).pow(e);
+    H root = H::two_adic_root();
     for (int i = lg; i < 32; ++i) root = root * root;
     *w = root;
     return true;
 }
-inline std::vector<HFr> domain_elements(size_t n, size_t count) {
-    HFr w;
+template <class H = HFr>
+inline std::vector<H> domain_elements(size_t n, size_t count) {
+    H w;
     domain_omega(domain_size(n), &w);
-    std::vector<HFr> el(count);
-    HFr p = HFr::one();
+    std::vector<H> el(count);
+    H p = H::one();
     for (size_t j = 0; j < count; ++j) {
         el[j] = p;
         p = p * w;
@@ -107,9 +110,10 @@ inline std::vector<uint32_t> build_twist(size_t size, size_t P, size_t dp1, int 
     }
     return out;
 }
+template <class H = HFr>
 inline std::vector<uint32_t> build_alpha(size_t n, int impl) {
     std::vector<uint32_t> out;
-    for (const HFr& a : domain_elements(n, n)) put_const(out, a, impl);
+    for (const H& a : domain_elements<H>(n, n)) put_const(out, a, impl);
     return out;
 }
 inline std::vector<uint32_t> build_pow2(size_t m, int impl) {
@@ -124,34 +128,36 @@ inline std::vector<uint32_t> build_pow2(size_t m, int impl) {
 
 // Lagrange basis over the points xs (distinct): basis[i][k] = coefficient k of
 // L_i(x) = A(x) / ((x - x_i) A'(x_i)),  A = prod (x - x_j)     (robust_interpolate.rs:351-376)
-inline std::vector<std::vector<HFr>> lagrange_basis(const std::vector<HFr>& xs) {
+template <class H>
+inline std::vector<std::vector<H>> lagrange_basis(const std::vector<H>& xs) {
     const size_t m = xs.size();
-    std::vector<HFr> A(m + 1, HFr::zero());
-    A[0] = HFr::one();
+    std::vector<H> A(m + 1, H::zero());
+    A[0] = H::one();
     size_t deg = 0;
-    for (const HFr& x : xs) {  // A *= (x - x_j)
-        const HFr nx = x.neg();
+    for (const H& x : xs) {  // A *= (x - x_j)
+        const H nx = x.neg();
         A[deg + 1] = A[deg];
         for (size_t k = deg; k > 0; --k) A[k] = A[k] * nx + A[k - 1];
         A[0] = A[0] * nx;
         ++deg;
     }
-    std::vector<std::vector<HFr>> basis(m, std::vector<HFr>(m, HFr::zero()));
+    std::vector<std::vector<H>> basis(m, std::vector<H>(m, H::zero()));
     for (size_t i = 0; i < m; ++i) {
         // synthetic division of A by (x - x_i): q[m-1] = A[m], q[k-1] = A[k] + x_i q[k]
-        std::vector<HFr> q(m);
+        std::vector<H> q(m);
         q[m - 1] = A[m];
         for (size_t k = m - 1; k > 0; --k) q[k - 1] = A[k] + xs[i] * q[k];
-        HFr denom = HFr::one();  // A'(x_i) = prod_{j != i} (x_i - x_j)
+        H denom = H::one();  // A'(x_i) = prod_{j != i} (x_i - x_j)
         for (size_t j = 0; j < m; ++j)
             if (j != i) denom = denom * (xs[i] - xs[j]);
-        const HFr inv = denom.inv();
+        const H inv = denom.inv();
         for (size_t k = 0; k < m; ++k) basis[i][k] = q[k] * inv;
     }
     return basis;
 }
-inline HFr horner(const std::vector<HFr>& p, const HFr& x) {
-    HFr acc = HFr::zero();
+template <class H>
+inline H horner(const std::vector<H>& p, const H& x) {
+    H acc = H::zero();
     for (size_t k = p.size(); k-- > 0;) acc = acc * x + p[k];
     return acc;
 }
@@ -160,10 +166,11 @@ inline HFr horner(const std::vector<HFr>& p, const HFr& x) {
 struct RecoverTables {
     std::vector<uint32_t> vm, bc;
 };
+template <class H = HFr>
 inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t, int impl) {
     const size_t m = d + 1, needed = d + t + 1;
-    std::vector<HFr> el = domain_elements(n, n);
-    std::vector<HFr> xs(m);
+    std::vector<H> el = domain_elements<H>(n, n);
+    std::vector<H> xs(m);
     for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[i]];
     auto basis = lagrange_basis(xs);
     RecoverTables T;

@@ -24,8 +24,8 @@ void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hi
     hipLaunchKernelGGL(k_validate_canonical, dim3((unsigned)((N + 255) / 256 ? (N + 255) / 256 : 1)), dim3(256), 0, s, a, N,
                        status);
 }
-void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, uint32_t* degree_out, hipStream_t s) {
+void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s) {
     hipLaunchKernelGGL(k_poly_degree, dim3((unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1)), dim3(256), 0, s, coeffs, G, m,
-                       degree_out);
+                       ew64, degree_out);
 }
 }

@@ -1,3 +1,4 @@
+#include "fr_gold.hpp"
 #include "kernels_eval.hpp"
 #include "launchers.hpp"
 namespace hbmpc {
@@ -5,20 +6,25 @@ void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, 
                          hipStream_t s) {
     const unsigned grid = (unsigned)((G + 255) / 256);
     if (impl == 0) hipLaunchKernelGGL((k_eval_generic<U29>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
-    else hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
 }
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s) {
     if (impl == 0) {
         if (p0) hipLaunchKernelGGL((k_batch_recover_generic<U29, true>), dim3(grid), dim3(256), 0, s, ra);
         else hipLaunchKernelGGL((k_batch_recover_generic<U29, false>), dim3(grid), dim3(256), 0, s, ra);
-    } else {
+    } else if (impl == 1) {
         if (p0) hipLaunchKernelGGL((k_batch_recover_generic<Sat32, true>), dim3(grid), dim3(256), 0, s, ra);
         else hipLaunchKernelGGL((k_batch_recover_generic<Sat32, false>), dim3(grid), dim3(256), 0, s, ra);
+    } else {
+        if (p0) hipLaunchKernelGGL((k_batch_recover_generic<Gold, true>), dim3(grid), dim3(256), 0, s, ra);
+        else hipLaunchKernelGGL((k_batch_recover_generic<Gold, false>), dim3(grid), dim3(256), 0, s, ra);
     }
 }
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s) {
     const unsigned grid = (unsigned)((S + 255) / 256);
     if (impl == 0) hipLaunchKernelGGL((k_matvec<U29>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
-    else hipLaunchKernelGGL((k_matvec<Sat32>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
+    else if (impl == 1) hipLaunchKernelGGL((k_matvec<Sat32>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
+    else hipLaunchKernelGGL((k_matvec<Gold>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
 }
 }

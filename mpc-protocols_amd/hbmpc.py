@@ -67,15 +67,26 @@ class Engine:
     """One hbmpc_ctx on one GPU.  Host-pointer calls take/return numpy U256 arrays; the
     dev_* calls take raw device pointers (ints, e.g. torch.Tensor.data_ptr()) and a stream."""
 
-    def __init__(self, device: int = 0, impl: str | None = None):
+    def __init__(self, device: int = 0, impl: str | None = None, field: str = "fr"):
+        """field: "fr" (bls12-381 Fr, U256 elements = numpy [..., 4] uint64) or "goldilocks" (8-byte elements =
+        numpy uint64; the hbmpc_gl_* entry points)"""
         self.L = lib()
         self.ctx = C.c_void_p()
-        rc = self.L.hbmpc_create(C.c_int(device), C.c_int(0), C.byref(self.ctx))
+        self.field = field
+        self.ebytes = {"fr": 32, "goldilocks": 8}[field]
+        self._pfx = "hbmpc_" if field == "fr" else "hbmpc_gl_"
+        rc = self.L.hbmpc_create(C.c_int(device), C.c_int(0 if field == "fr" else 1), C.byref(self.ctx))
         if rc != 0:
             msg = self.L.hbmpc_last_error(None)
             raise HbmpcError(f"hbmpc_create(device={device}) failed with code {rc}: {msg.decode() if msg else ''}")
         if impl is not None:
             self.set_impl(impl)
+
+    def _f(self, name):  # the entry point of this context's field
+        return getattr(self.L, self._pfx + name)
+
+    def _new(self, shape):  # zeroed output array of field elements
+        return u256(shape) if self.field == "fr" else np.zeros(tuple(shape), dtype=np.uint64)
 
     def close(self):
         if self.ctx:
@@ -103,40 +114,40 @@ class Engine:
     def compute_shares(self, coeffs, n, d):
         coeffs = np.ascontiguousarray(coeffs)
         B = coeffs.shape[0]
-        out = u256((n, B))
-        rc = self.L.hbmpc_compute_shares(self.ctx, _p(coeffs), C.c_size_t(B), C.c_size_t(n), C.c_size_t(d), _p(out))
+        out = self._new((n, B))
+        rc = self._f("compute_shares")(self.ctx, _p(coeffs), C.c_size_t(B), C.c_size_t(n), C.c_size_t(d), _p(out))
         return rc, out
 
     def make_vandermonde(self, n, d):
-        out = u256((n, d + 1))
-        rc = self.L.hbmpc_make_vandermonde(self.ctx, C.c_size_t(n), C.c_size_t(d), _p(out))
+        out = self._new((n, d + 1))
+        rc = self._f("make_vandermonde")(self.ctx, C.c_size_t(n), C.c_size_t(d), _p(out))
         return rc, out
 
     def vandermonde_apply(self, x, n, d):
         x = np.ascontiguousarray(x)
         G = x.shape[0]
-        out = u256((n, G))
-        rc = self.L.hbmpc_vandermonde_apply(self.ctx, _p(x), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), _p(out))
+        out = self._new((n, G))
+        rc = self._f("vandermonde_apply")(self.ctx, _p(x), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), _p(out))
         return rc, out
 
     def batch_recover(self, sender_ids, evals, n, d, t):
         evals = np.ascontiguousarray(evals)
         S = len(sender_ids)
-        G = evals.shape[1] if evals.ndim == 3 else 0
-        out = u256((G, d + 1))
+        G = evals.shape[1] if evals.ndim == (3 if self.field == "fr" else 2) else 0
+        out = self._new((G, d + 1))
         nco = np.zeros(G, dtype=np.uint32)
         st = np.zeros(G, dtype=np.uint8)
-        rc = self.L.hbmpc_batch_recover(self.ctx, _p(_sz(sender_ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
+        rc = self._f("batch_recover")(self.ctx, _p(_sz(sender_ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
                                         C.c_size_t(n), C.c_size_t(d), C.c_size_t(t), _p(out), _p(nco), _p(st))
         return rc, out, nco, st
 
     def batch_recover_p0(self, sender_ids, evals, n, d, t):
         evals = np.ascontiguousarray(evals)
         S = len(sender_ids)
-        G = evals.shape[1] if evals.ndim == 3 else 0
-        out = u256((G,))
+        G = evals.shape[1] if evals.ndim == (3 if self.field == "fr" else 2) else 0
+        out = self._new((G,))
         st = np.zeros(G, dtype=np.uint8)
-        rc = self.L.hbmpc_batch_recover_p0(self.ctx, _p(_sz(sender_ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
+        rc = self._f("batch_recover_p0")(self.ctx, _p(_sz(sender_ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
                                            C.c_size_t(n), C.c_size_t(d), C.c_size_t(t), _p(out), _p(st))
         return rc, out, st
 
@@ -144,52 +155,52 @@ class Engine:
         vals = np.ascontiguousarray(vals)
         S = len(ids)
         cap = (int(degrees[0]) + 1) if S else 1
-        out = u256((max(cap, 1),))
+        out = self._new((max(cap, 1),))
         nco = C.c_size_t(0)
-        sec = u256((1,))
-        rc = self.L.hbmpc_recover_secret(self.ctx, _p(_sz(ids)), _p(_sz(degrees)), _p(vals), C.c_size_t(S),
+        sec = self._new((1,))
+        rc = self._f("recover_secret")(self.ctx, _p(_sz(ids)), _p(_sz(degrees)), _p(vals), C.c_size_t(S),
                                          C.c_size_t(n), C.c_size_t(t), _p(out), C.byref(nco), _p(sec))
         return rc, out[: nco.value], sec[0]
 
     def gao_rs_decode(self, received, k, n, erasures):
         received = np.ascontiguousarray(received)
-        out = u256((max(k, 1),))
+        out = self._new((max(k, 1),))
         nco = C.c_size_t(0)
-        rc = self.L.hbmpc_gao_rs_decode(self.ctx, _p(received), C.c_size_t(k), C.c_size_t(n), _p(_sz(erasures)),
+        rc = self._f("gao_rs_decode")(self.ctx, _p(received), C.c_size_t(k), C.c_size_t(n), _p(_sz(erasures)),
                                         C.c_size_t(len(erasures)), _p(out), C.byref(nco))
         return rc, out[: nco.value]
 
     def nonrobust_recover_secret(self, ids, degrees, vals, n):
         vals = np.ascontiguousarray(vals)
         S = len(ids)
-        out = u256((max(S, 1),))
+        out = self._new((max(S, 1),))
         nco = C.c_size_t(0)
-        sec = u256((1,))
-        rc = self.L.hbmpc_nonrobust_recover_secret(self.ctx, _p(_sz(ids)), _p(_sz(degrees)), _p(vals), C.c_size_t(S),
+        sec = self._new((1,))
+        rc = self._f("nonrobust_recover_secret")(self.ctx, _p(_sz(ids)), _p(_sz(degrees)), _p(vals), C.c_size_t(S),
                                                    C.c_size_t(n), _p(out), C.byref(nco), _p(sec))
         return rc, out[: nco.value], sec[0]
 
     def batch_interpolate(self, ids, evals, n):
         evals = np.ascontiguousarray(evals)
         S, G = len(ids), evals.shape[1]
-        co = u256((G, S))
+        co = self._new((G, S))
         deg = np.zeros(G, dtype=np.uint32)
-        rc = self.L.hbmpc_batch_interpolate(self.ctx, _p(_sz(ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
+        rc = self._f("batch_interpolate")(self.ctx, _p(_sz(ids)), C.c_size_t(S), _p(evals), C.c_size_t(G),
                                             C.c_size_t(n), _p(co), _p(deg))
         return rc, co, deg
 
     def _ew(self, name, ins, n_out=1, extra=()):
         ins = [np.ascontiguousarray(a) for a in ins]
         N = ins[0].shape[0]
-        outs = [u256((N,)) for _ in range(n_out)]
+        outs = [self._new((N,)) for _ in range(n_out)]
         args = [self.ctx] + [_p(a) for a in ins] + [C.c_size_t(e) for e in extra] + [C.c_size_t(N)] + [_p(o) for o in outs]
-        rc = getattr(self.L, name)(*args)
+        rc = getattr(self.L, name.replace("hbmpc_", self._pfx, 1))(*args)
         return (rc, *outs)
 
     def fr_op(self, op, a, b):
         a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
-        out = u256((a.shape[0],))
-        rc = self.L.hbmpc_fr_op(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), _p(a), _p(b),
+        out = self._new((a.shape[0],))
+        rc = self._f("fr_op")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), _p(a), _p(b),
                                 C.c_size_t(a.shape[0]), _p(out))
         return rc, out
 
@@ -208,7 +219,7 @@ class Engine:
     def truncpr_rdash(self, r_bits, m):
         r_bits = np.ascontiguousarray(r_bits)
         N = r_bits.shape[1]
-        out = u256((N,))
+        out = self._new((N,))
         rc = self.L.hbmpc_truncpr_rdash(self.ctx, _p(r_bits), C.c_size_t(m), C.c_size_t(N), _p(out))
         return rc, out
 
@@ -244,7 +255,7 @@ class Engine:
         assert rc == 0, self.last_error()
 
     def dev_fr_op(self, op, a_d, b_d, N, out_d, stream=0):
-        return self.L.hbmpc_dev_fr_op(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), C.c_void_p(a_d),
+        return self._f("dev_fr_op")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), C.c_void_p(a_d),
                                       C.c_void_p(b_d), C.c_size_t(N), C.c_void_p(out_d), C.c_void_p(stream))
 
     def sync(self, stream=0):
@@ -253,22 +264,22 @@ class Engine:
             raise HbmpcError(f"stream sync -> {rc}: {self.last_error()}")
 
     def dev_compute_shares(self, coeffs_d, B, n, d, out_d, stream=0):
-        return self.L.hbmpc_dev_compute_shares(self.ctx, C.c_void_p(coeffs_d), C.c_size_t(B), C.c_size_t(n),
+        return self._f("dev_compute_shares")(self.ctx, C.c_void_p(coeffs_d), C.c_size_t(B), C.c_size_t(n),
                                                C.c_size_t(d), C.c_void_p(out_d), C.c_void_p(stream))
 
     def dev_vandermonde_apply(self, x_d, G, n, d, y_d, stream=0):
-        return self.L.hbmpc_dev_vandermonde_apply(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),
+        return self._f("dev_vandermonde_apply")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),
                                                   C.c_size_t(d), C.c_void_p(y_d), C.c_void_p(stream))
 
     def dev_batch_recover(self, sender_ids, evals_d, G, n, d, t, out_d, nco_d=0, status_d=0, summary_d=0, stream=0,
                           p0=False):
         ids = _sz(sender_ids)
         if p0:
-            return self.L.hbmpc_dev_batch_recover_p0(self.ctx, _p(ids), C.c_size_t(len(sender_ids)),
+            return self._f("dev_batch_recover_p0")(self.ctx, _p(ids), C.c_size_t(len(sender_ids)),
                                                      C.c_void_p(evals_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
                                                      C.c_size_t(t), C.c_void_p(out_d), C.c_void_p(status_d),
                                                      C.c_void_p(summary_d), C.c_void_p(stream))
-        return self.L.hbmpc_dev_batch_recover(self.ctx, _p(ids), C.c_size_t(len(sender_ids)), C.c_void_p(evals_d),
+        return self._f("dev_batch_recover")(self.ctx, _p(ids), C.c_size_t(len(sender_ids)), C.c_void_p(evals_d),
                                               C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(t),
                                               C.c_void_p(out_d), C.c_void_p(nco_d), C.c_void_p(status_d),
                                               C.c_void_p(summary_d), C.c_void_p(stream))
@@ -276,7 +287,7 @@ class Engine:
     def dev_batch_recover_strided(self, sender_ids, evals_d, row_stride, G, n, d, t, out_d, p0=False, nco_d=0,
                                   status_d=0, summary_d=0, stream=0):
         ids = _sz(sender_ids)
-        return self.L.hbmpc_dev_batch_recover_strided(self.ctx, _p(ids), C.c_size_t(len(sender_ids)),
+        return self._f("dev_batch_recover_strided")(self.ctx, _p(ids), C.c_size_t(len(sender_ids)),
                                                       C.c_void_p(evals_d), C.c_size_t(row_stride), C.c_size_t(G),
                                                       C.c_size_t(n), C.c_size_t(d), C.c_size_t(t),
                                                       C.c_int(1 if p0 else 0), C.c_void_p(out_d), C.c_void_p(nco_d),
@@ -285,7 +296,7 @@ class Engine:
     def dev_elem(self, name, ptrs, N, extra=(), stream=0):
         args = [self.ctx] + [C.c_void_p(p) for p in ptrs[: name_inputs(name)]] + [C.c_size_t(e) for e in extra] + \
                [C.c_size_t(N)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
-        return getattr(self.L, "hbmpc_dev_" + name)(*args)
+        return getattr(self.L, self._pfx + "dev_" + name)(*args)
 
     # ---- wire codec ----
     def dev_pack_fvec(self, rows_d, row_stride, G, n_rows, payloads_d, payload_stride_bytes, stream=0):

@@ -1,0 +1,276 @@
+"""GPU parity tests of the Goldilocks variants: the hbmpc_gl_* entry points,
+called through the C ABI, against oracle/spec_gl.py (the same restatement as for Fr with the field constants of
+mpc/src/common/math/goldilocks.rs:4-13).  Bar: bit-exact.  The cases mirror tests/test_gpu_parity.py: seeded
+random inputs at sizes the big-int oracle finishes in seconds, the reference's edge cases (corruption inside and
+outside the verify window, missing senders, too many errors, erasures, degree checks), field edge values, and
+size-independent properties at 2^20 chunks."""
+import itertools
+import random
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle.spec_gl import P, S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = load_package().Engine(0, field="goldilocks")
+    yield e
+    e.close()
+
+
+def rnd(seed, *shape):
+    rng = random.Random(seed)
+    return np.array([rng.randrange(P) for _ in range(int(np.prod(shape)))], dtype=np.uint64).reshape(shape)
+
+
+EDGE = [0, 1, 2, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 63), P >> 1, (P >> 1) + 1, 0xFFFFFFFF00000000, 7]
+
+
+def test_field_ops(eng):
+    a, b = rnd(1, 4000), rnd(2, 4000)
+    k = len(EDGE)
+    a[:k * k] = np.repeat(np.array(EDGE, dtype=np.uint64), k)
+    b[:k * k] = np.tile(np.array(EDGE, dtype=np.uint64), k)
+    ai, bi = [int(x) for x in a], [int(x) for x in b]
+    for op, fn in (("add", lambda x, y: (x + y) % P), ("sub", lambda x, y: (x - y) % P), ("mul", lambda x, y: x * y % P)):
+        rc, got = eng.fr_op(op, a, b)
+        assert rc == 0
+        assert [int(x) for x in got] == [fn(x, y) for x, y in zip(ai, bi)], op
+
+
+def test_context_serves_one_field(eng):
+    fr = load_package().Engine(0)
+    x = np.zeros((4, 3), dtype=np.uint64)
+    assert fr.L.hbmpc_gl_compute_shares(fr.ctx, x.ctypes.data, 4, 6, 2, x.ctypes.data) == 5          # TypeMismatch
+    assert eng.L.hbmpc_compute_shares(eng.ctx, x.ctypes.data, 4, 6, 2, x.ctypes.data) == 5
+    assert eng.L.hbmpc_set_field_impl(eng.ctx, 1) == 5
+    fr.close()
+
+
+@pytest.mark.parametrize("n,d", [(4, 1), (6, 2), (7, 2), (10, 3), (16, 5), (16, 10), (16, 15), (31, 10), (33, 7), (100, 33),
+                                 (255, 84)])
+def test_compute_shares_and_vandermonde_vs_oracle(eng, n, d):
+    G = 37 if n > 64 else 193
+    x = rnd(n * 1000 + d, G, d + 1)
+    x[0, :] = 0
+    x[1, :] = P - 1
+    rc, y = eng.compute_shares(x, n, d)
+    assert rc == 0 and y.shape == (n, G)
+    for g in (0, 1, 2, G // 2, G - 1):
+        want = [s.v for s in S.compute_shares([int(c) for c in x[g]], n, d)]
+        assert [int(v) for v in y[:, g]] == want
+    rc, y2 = eng.vandermonde_apply(x, n, d)
+    assert rc == 0 and np.array_equal(y, y2)
+    rc, v = eng.make_vandermonde(n, d)
+    assert rc == 0 and [[int(c) for c in row] for row in v] == S.make_vandermonde(n, d)
+    # full check of every chunk through the Vandermonde rows (numpy object arithmetic)
+    V = np.array(S.make_vandermonde(n, d), dtype=object)
+    want_all = (V.dot(x.astype(object).T)) % P
+    assert np.array_equal(y.astype(object), want_all)
+
+
+def test_eval_errors_and_empty(eng):
+    x = rnd(3, 5, 3)
+    assert eng.compute_shares(x, 2, 2)[0] == 4          # n <= degree: InvalidInput (robust_interpolate.rs:59-64)
+    rc, y = eng.compute_shares(np.zeros((0, 3), dtype=np.uint64), 6, 2)
+    assert rc == 0 and y.shape == (6, 0)
+
+
+def encode(eng, x, n, d):
+    rc, y = eng.vandermonde_apply(x, n, d)
+    assert rc == 0
+    return y
+
+
+@pytest.mark.parametrize("n,t,d", [(4, 1, 1), (7, 2, 2), (10, 3, 3), (16, 5, 5), (16, 5, 10), (31, 10, 10), (64, 21, 21)])
+def test_batch_recover_vs_oracle(eng, n, t, d):
+    G = 120
+    x = rnd(n + 77 * d, G, d + 1)
+    y = encode(eng, x, n, d)
+    rng = random.Random(n * 31 + d)
+    # chunks 0..39 clean; 40..79: <= t errors anywhere; 80..99: errors only outside the verify window;
+    # 100..109: more than t errors; 110..119: one error in the base set
+    for g in range(40, 80):
+        for s in rng.sample(range(n), rng.randint(1, t)):
+            y[s, g] = (int(y[s, g]) + rng.randrange(1, P)) % P
+    needed = d + t + 1
+    for g in range(80, 100):
+        if needed < n:
+            for s in rng.sample(range(needed, n), min(t, n - needed)):
+                y[s, g] = (int(y[s, g]) + 1) % P
+    for g in range(100, 110):
+        for s in rng.sample(range(n), min(n, t + 1 + (n - d - 2 * t - 1))):
+            y[s, g] = (int(y[s, g]) + rng.randrange(1, P)) % P
+    for g in range(110, 120):
+        y[rng.randrange(d + 1), g] ^= np.uint64(1)
+    ids = list(range(n))
+    rng.shuffle(ids)                                      # arrival order
+    rc, co, nco, st = eng.batch_recover(ids, y[ids], n, d, t)
+    ev = [(i, [int(v) for v in y[i]]) for i in ids]
+    for g in range(G):
+        shares = [S.Share(col[g], i, d) for i, col in ev]
+        try:
+            coeffs, _ = S.recover_secret(shares, n, t)
+            ok = True
+        except S.ShareErr as e:
+            ok, code = False, e.code
+        if ok:
+            got = [int(v) for v in co[g][: nco[g]]] if st[g] == 1 else [int(v) for v in co[g]]
+            assert st[g] in (0, 1), (g, st[g])
+            want = coeffs + [0] * (len(got) - len(coeffs))
+            assert got == want, g
+        else:
+            assert st[g] == code, (g, st[g], code)
+    any_fail = any(st[g] not in (0, 1) for g in range(G))
+    assert (rc != 0) == any_fail
+    # P(0)-only variant on the decodable part
+    good = [g for g in range(G) if st[g] in (0, 1)]
+    rc, sec, st0 = eng.batch_recover_p0(ids, np.ascontiguousarray(y[ids][:, good]), n, d, t)
+    assert rc == 0 and [int(v) for v in sec] == [int(co[g][0]) for g in good]
+
+
+def test_batch_recover_validation_and_missing_senders(eng):
+    n, t, d = 10, 3, 3
+    x = rnd(5, 50, d + 1)
+    y = encode(eng, x, n, d)
+    ids = [9, 0, 3, 4, 6, 1, 8]                            # exactly d + t + 1 = 7 senders, unsorted
+    rc, co, nco, st = eng.batch_recover(ids, y[ids], n, d, t)
+    assert rc == 0 and np.array_equal(co, x) and not st.any()
+    assert eng.batch_recover(ids[:6], y[ids[:6]], n, d, t)[0] == 4     # not enough evaluations
+    assert eng.batch_recover([0, 0, 1, 2, 3, 4, 5], y[:7], n, d, t)[0] == 4  # duplicate id
+    assert eng.batch_recover([0, 1, 2, 3, 4, 5, 10], y[:7], n, d, t)[0] == 4  # id out of range
+    assert eng.batch_recover(list(range(10)), y, 9, d, t)[0] == 4      # n < 3t + 1
+
+
+def test_recover_secret_all_corruption_combinations(eng):
+    # robust_interpolate.rs test_robust_interpolate_all_corruption_combinations, in the small field
+    n, t, d = 7, 2, 2
+    coeffs = [11, 22, 33]
+    base = S.compute_shares(coeffs, n, d)
+    for k in range(0, t + 2):
+        for bad in itertools.combinations(range(n), k):
+            vals = np.array([(s.v + (97 + i if i in bad else 0)) % P for i, s in enumerate(base)], dtype=np.uint64)
+            rc, co, sec = eng.recover_secret(list(range(n)), [d] * n, vals, n, t)
+            try:
+                want, wsec = S.recover_secret([S.Share(int(v), i, d) for i, v in enumerate(vals)], n, t)
+                assert rc == 0 and [int(c) for c in co] == want and int(sec) == wsec, bad
+            except S.ShareErr as e:
+                assert rc == e.code, (bad, rc, e.code)
+
+
+def test_recover_secret_trims_and_errors(eng):
+    n, t = 7, 2
+    sh = S.compute_shares([5, 0, 0], n, 2)                 # degree-2 sharing of a constant polynomial
+    vals = np.array([s.v for s in sh], dtype=np.uint64)
+    rc, co, sec = eng.recover_secret(list(range(n)), [2] * n, vals, n, t)
+    assert rc == 0 and [int(c) for c in co] == [5] and int(sec) == 5
+    assert eng.recover_secret(list(range(n)), [2] * 6 + [1], vals, n, t)[0] == 2      # DegreeMismatch
+    assert eng.recover_secret([0, 1, 2, 3], [2] * 4, vals[:4], n, t)[0] == 4          # not enough shares
+
+
+def test_gao_rs_decode(eng):
+    n, k = 10, 4
+    msg = [3, 1, 4, 1]
+    cw = [S.p_eval(msg, S.domain_element(n, i)) for i in range(n)]
+    for erasures, errors in (([], []), ([2, 7], [0]), ([1], [3, 9]), ([0, 1, 2, 3, 4, 5], []), ([], [0, 1, 2])):
+        rec = list(cw)
+        for i in errors:
+            rec[i] = (rec[i] + 12345) % P
+        rc, co = eng.gao_rs_decode(np.array(rec, dtype=np.uint64), k, n, erasures)
+        try:
+            want = S.gao_rs_decode(rec, k, n, erasures)
+            assert rc == 0 and [int(c) for c in co] == want, (erasures, errors)
+        except S.ShareErr as e:
+            assert rc == e.code, (erasures, errors, rc)
+
+
+def test_nonrobust_and_batch_interpolate(eng):
+    n, t = 10, 3
+    ids = [7, 2, 9, 0, 4, 5, 1]
+    poly = [9, 8, 7, 6]
+    vals = np.array([S.p_eval(poly, S.domain_element(n, i)) for i in ids], dtype=np.uint64)
+    rc, co, sec = eng.nonrobust_recover_secret(ids, [6] * len(ids), vals, n)
+    assert rc == 0 and [int(c) for c in co] == poly and int(sec) == 9
+    assert eng.nonrobust_recover_secret(ids, [2] * len(ids), vals, n)[0] == 2          # degree 3 > 2
+    # RanDouSha verifier shape: G columns through S = 2t + 1 points, degree() per column
+    S_, G = 2 * t + 1, 64
+    pol = rnd(8, G, S_)
+    pol[::2, t + 1:] = 0                                    # even columns have degree <= t
+    pol[4, :] = 0                                           # the zero polynomial (degree() = 0)
+    idl = list(range(S_))
+    ev = np.array([[S.p_eval([int(c) for c in pol[g]], S.domain_element(n, i)) for g in range(G)] for i in idl],
+                  dtype=np.uint64)
+    rc, co, deg = eng.batch_interpolate(idl, ev, n)
+    assert rc == 0 and np.array_equal(co, pol)
+    assert [int(x) for x in deg] == [S.p_degree(S.p_norm([int(c) for c in pol[g]])) for g in range(G)]
+
+
+def test_elementwise_vs_oracle(eng):
+    N = 500
+    a, b, r2t, rt, c, x, y, d, e = (rnd(20 + i, N) for i in range(9))
+    a[:len(EDGE)] = np.array(EDGE, dtype=np.uint64)
+    b[:len(EDGE)] = np.array(EDGE[::-1], dtype=np.uint64)
+    I = lambda v: [int(q) for q in v]  # noqa: E731
+    rc, out = eng.triple_local(a, b, r2t)
+    assert rc == 0 and I(out) == [(p * q - r) % P for p, q, r in zip(I(a), I(b), I(r2t))]
+    rc, out = eng.triple_finalize(rt, c)
+    assert rc == 0 and I(out) == [(p + q) % P for p, q in zip(I(rt), I(c))]
+    rc, dsh, esh = eng.beaver_open_shares(a, b, x, y)
+    assert rc == 0 and I(dsh) == [(p - q) % P for p, q in zip(I(a), I(x))] and I(esh) == [(p - q) % P for p, q in zip(I(b), I(y))]
+    rc, z = eng.beaver_finalize(c, x, y, d, e)
+    want = [S.beaver_finalize(S.Share(cc, 0, 1), S.Share(xx, 0, 1), S.Share(yy, 0, 1), dd, ee).v
+            for cc, xx, yy, dd, ee in zip(I(c), I(x), I(y), I(d), I(e))]
+    assert rc == 0 and I(z) == want
+
+
+def test_full_size_roundtrip_and_linearity(eng):
+    """2^20 chunks, n = 16, t = 5, d = 5 (the shape of BASELINE configs[1] in the small field): device-resident
+    encode -> erase t senders -> decode round trip; linearity checksum; strided decode of a sub-range."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, t, d, G = 16, 5, 5, 1 << 20
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    hi = torch.randint(0, 0xFFFFFFFF, (G, d + 1), dtype=torch.int64, device=dev, generator=g)  # < 2^32 - 1: canonical
+    lo = torch.randint(0, 1 << 32, (G, d + 1), dtype=torch.int64, device=dev, generator=g)
+    x = (hi << 32) | lo
+    y = torch.empty((n, G), dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), s) == 0
+    keep = [15, 3, 8, 0, 12, 5, 9, 1, 14, 7, 2]            # d + t + 1 = 11 of the 16 senders, arrival order
+    ysub = y[keep].contiguous()
+    co = torch.empty((G, d + 1), dtype=torch.int64, device=dev)
+    st = torch.empty((G,), dtype=torch.uint8, device=dev)
+    summ = torch.zeros((4,), dtype=torch.int32, device=dev)
+    assert eng.dev_batch_recover(keep, ysub.data_ptr(), G, n, d, t, co.data_ptr(), 0, st.data_ptr(), summ.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    assert bool((co == x).all()) and int(st.max()) == 0 and summ.tolist()[:2] == [0, 0]
+    # sampled comparison with the oracle
+    xs = x[:: G // 16].cpu().numpy().view(np.uint64)
+    ys = y[:, :: G // 16].cpu().numpy().view(np.uint64)
+    for i in range(xs.shape[0]):
+        assert [int(v) for v in ys[:, i]] == [sh.v for sh in S.compute_shares([int(c) for c in xs[i]], n, d)]
+    # linearity: encode(x) + encode(x') == encode(x + x') on the device
+    x2 = torch.roll(x, 1, 0)
+    y2, y3, xsum = torch.empty_like(y), torch.empty_like(y), torch.empty_like(x)
+    assert eng.dev_vandermonde_apply(x2.data_ptr(), G, n, d, y2.data_ptr(), s) == 0
+    assert eng.dev_fr_op("add", x.data_ptr(), x2.data_ptr(), G * (d + 1), xsum.data_ptr(), s) == 0
+    assert eng.dev_vandermonde_apply(xsum.data_ptr(), G, n, d, y3.data_ptr(), s) == 0
+    ysum = torch.empty_like(y)
+    assert eng.dev_fr_op("add", y.data_ptr(), y2.data_ptr(), n * G, ysum.data_ptr(), s) == 0
+    torch.cuda.synchronize()
+    assert bool((ysum == y3).all())
+    # corrupt t senders in every 64th chunk: OEC/Gao fallback on the device, P(0)-only, strided rows
+    yc = y.clone()
+    yc[:t, ::64] ^= 1
+    sec = torch.empty((G,), dtype=torch.int64, device=dev)
+    assert eng.dev_batch_recover_strided(list(range(n)), yc.data_ptr(), G, G, n, d, t, sec.data_ptr(), p0=True,
+                                         status_d=st.data_ptr(), summary_d=summ.data_ptr(), stream=s) == 0
+    torch.cuda.synchronize()
+    assert bool((sec == x[:, 0]).all()) and summ.tolist()[:2] == [G // 64, 0]
+    assert int(st[::64].min()) == 1 and int(st[1::64].max()) == 0
