@@ -271,6 +271,7 @@ def extra_measurements(eng, torch, dev, stream, cref):
                            "hbm_frac": 128 * N / ms / 1e6 / HBM_PEAK_GBS}
     del a, b, c, o
     res.update(pipeline_measurements(eng, torch, dev, stream, ev_time))
+    res.update(goldilocks_measurements(torch, dev, stream, ev_time))
     # integer-ALU ceiling: register-resident modmul chain (2 modmuls per iteration per lane)
     for impl in ("u29", "sat32"):
         eng.set_impl(impl)
@@ -279,6 +280,46 @@ def extra_measurements(eng, torch, dev, stream, cref):
         ms = ev_time(lambda: eng.dev_modmul_ubench(buf.data_ptr(), threads, iters, stream), reps=3, warm=1)
         res[f"modmul_per_s_{impl}"] = threads * (2 * iters + 2) / ms * 1e3
     eng.set_impl("u29")
+    return res
+
+
+def goldilocks_measurements(torch, dev, stream, ev_time):
+    """the small-field variants at the shapes of configs 2 and 3 (8-byte elements)."""
+    from __graft_entry__ import load_package
+    from oracle.spec_gl import S as SG  # checker only
+    eng = load_package().Engine(dev.index or 0, field="goldilocks")
+    res = {}
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC0FFEE05)
+
+    def rand(*shape):  # canonical: high word < 2^32 - 1
+        hi = torch.randint(0, 0xFFFFFFFF, shape, dtype=torch.int64, device=dev, generator=gen)
+        lo = torch.randint(0, 1 << 32, shape, dtype=torch.int64, device=dev, generator=gen)
+        return (hi << 32) | lo
+
+    for tag, n, t, d, G in (("gl_cfg2_compute_shares", 16, 5, 5, 1 << 20), ("gl_cfg3", 31, 10, 10, 1 << 20)):
+        x = rand(G, d + 1)
+        y = torch.empty((n, G), dtype=torch.int64, device=dev)
+        ms = ev_time(lambda: eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), stream))
+        torch.cuda.synchronize()
+        xs, ys = x[:4].cpu().numpy().view(np.uint64), y[:, :4].cpu().numpy().view(np.uint64)
+        for i in range(4):
+            assert [int(v) for v in ys[:, i]] == [sh.v for sh in SG.compute_shares([int(c) for c in xs[i]], n, d)]
+        by = (d + 1 + n) * 8 * G
+        res[tag + ("" if "shares" in tag else "_encode")] = {"share_evals_per_s": n * G / ms * 1e3, "ms": ms,
+                                                             "GBps_algorithmic": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS}
+        if tag == "gl_cfg3":
+            co = torch.empty((G, d + 1), dtype=torch.int64, device=dev)
+            st = torch.empty((G,), dtype=torch.uint8, device=dev)
+            summ = torch.zeros((4,), dtype=torch.int32, device=dev)
+            ms = ev_time(lambda: eng.dev_batch_recover(list(range(n)), y.data_ptr(), G, n, d, t, co.data_ptr(), 0,
+                                                       st.data_ptr(), summ.data_ptr(), stream))
+            torch.cuda.synchronize()
+            assert bool((co == x).all()) and int(st.max()) == 0
+            by = (d + t + 1 + d + 1) * 8 * G
+            res["gl_cfg3_decode"] = {"recons_per_s": G / ms * 1e3, "ms": ms, "GBps_algorithmic": by / ms / 1e6,
+                                     "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS}
+    eng.close()
     return res
 
 

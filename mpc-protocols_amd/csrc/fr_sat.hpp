@@ -17,6 +17,7 @@ namespace hbmpc {
 struct Sat32 {
     static constexpr int NL = 8;
     static constexpr int EW = 8;  // u32 words per stored element
+    static constexpr int EVAL_WAVES = 2;
     static constexpr int MAX_DOT_TERMS = 1 << 30;
 
     struct E {

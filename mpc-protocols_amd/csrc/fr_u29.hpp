@@ -37,6 +37,7 @@ struct U29 {
     // A 64-bit column holds 2^64 / 2^58 = 64 products of normalised limbs.  A term adds up to 9 per column,
     // the reduction up to 8 more (m * r) plus carries: 9 T + 9 <= 64  =>  T <= 6 terms between folds.
     static constexpr int EW = 8;  // u32 words per stored element
+    static constexpr int EVAL_WAVES = 2;  // waves per SIMD the register-resident FFT kernels are compiled for
     static constexpr int MAX_DOT_TERMS = 6;
 
     struct E {

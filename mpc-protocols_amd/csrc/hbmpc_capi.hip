@@ -176,7 +176,7 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     ctx->impl = impl;
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on) {
+extern "C" ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on) {  // either field
     if (!ctx) return InvalidInput;
     ctx->force_generic = on != 0;
     return ShareSuccess;
@@ -220,26 +220,35 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
                                 hipStream_t s) {
     const size_t size = domain_size(n), dp1 = d + 1;
     const int impl = ctx->impl;
-    if (impl == IMPL_U29 && size <= 16 && !ctx->force_generic) {
+    const bool gold = impl == IMPL_GOLD;
+    if ((impl == IMPL_U29 || gold) && size <= 16 && !ctx->force_generic) {
         const uint32_t* tw;
-        ShareErrorCode rc = get_table(ctx, key("tw", {size}, impl), [&] { return build_twiddles(size, impl); }, &tw);
+        ShareErrorCode rc = get_table(ctx, key("tw", {size}, impl), [&] {
+            return gold ? build_twiddles<HGl>(size, impl) : build_twiddles<HFr>(size, impl);
+        }, &tw);
         if (rc != ShareSuccess) return rc;
         const int lg = ilog2(size), c = (int)dp1, nn = (int)n;
-        if (lg < 4 ? launch_fft1_lo(lg, c, x, G, nn, tw, y, s)
-                   : (launch_fft1_16a(c, x, G, nn, tw, y, s) || launch_fft1_16b(c, x, G, nn, tw, y, s) ||
-                      launch_fft1_16c(c, x, G, nn, tw, y, s) || launch_fft1_16d(c, x, G, nn, tw, y, s)))
+        if (gold ? launch_gold_fft1(lg, c, x, G, nn, tw, y, s)
+                 : (lg < 4 ? launch_fft1_lo(lg, c, x, G, nn, tw, y, s)
+                           : (launch_fft1_16a(c, x, G, nn, tw, y, s) || launch_fft1_16b(c, x, G, nn, tw, y, s) ||
+                              launch_fft1_16c(c, x, G, nn, tw, y, s) || launch_fft1_16d(c, x, G, nn, tw, y, s))))
             return ShareSuccess;
-    } else if (impl == IMPL_U29 && size <= 256 && dp1 <= 32 && !ctx->force_generic) {
+    } else if ((impl == IMPL_U29 || gold) && size <= 256 && dp1 <= 32 && !ctx->force_generic) {
         const size_t P = size / 16;
         const uint32_t *tw16, *twist;
-        ShareErrorCode rc = get_table(ctx, key("tw", {16}, impl), [&] { return build_twiddles(16, impl); }, &tw16);
+        ShareErrorCode rc = get_table(ctx, key("tw", {16}, impl), [&] {
+            return gold ? build_twiddles<HGl>(16, impl) : build_twiddles<HFr>(16, impl);
+        }, &tw16);
         if (rc != ShareSuccess) return rc;
-        rc = get_table(ctx, key("twist", {size, dp1}, impl), [&] { return build_twist(size, P, dp1, impl); }, &twist);
+        rc = get_table(ctx, key("twist", {size, dp1}, impl), [&] {
+            return gold ? build_twist<HGl>(size, P, dp1, impl) : build_twist<HFr>(size, P, dp1, impl);
+        }, &twist);
         if (rc != ShareSuccess) return rc;
         const int c = (int)dp1, nn = (int)n, pp = (int)P;
-        if (launch_fftP_a(c, x, G, nn, pp, tw16, twist, y, s) || launch_fftP_b(c, x, G, nn, pp, tw16, twist, y, s) ||
-            launch_fftP_c(c, x, G, nn, pp, tw16, twist, y, s) || launch_fftP_d(c, x, G, nn, pp, tw16, twist, y, s) ||
-            launch_fftP_fold(c, x, G, nn, pp, tw16, twist, y, s))
+        if (gold ? launch_gold_fftP(c, x, G, nn, pp, tw16, twist, y, s)
+                 : (launch_fftP_a(c, x, G, nn, pp, tw16, twist, y, s) || launch_fftP_b(c, x, G, nn, pp, tw16, twist, y, s) ||
+                    launch_fftP_c(c, x, G, nn, pp, tw16, twist, y, s) || launch_fftP_d(c, x, G, nn, pp, tw16, twist, y, s) ||
+                    launch_fftP_fold(c, x, G, nn, pp, tw16, twist, y, s)))
             return ShareSuccess;
     }
     const uint32_t* alpha;

@@ -15,6 +15,7 @@
 // wave-tile = 64 chunks, rows padded by 16 B so the per-lane ds_read_b128 is bank-conflict free);
 // output party-major y[n][G]: a wave stores 2 KiB contiguous per party.
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "fr_sat.hpp"
@@ -146,22 +147,26 @@ constexpr int fft_max_vb() {
 // ---------------------------------------------------------------------------------------------
 constexpr int EVAL_TILE = 64;  // chunks per wave-tile (= one wavefront)
 
-HB_DEV int tile_pitch_words(int dp1) { return dp1 * 8 + 4; }
+// EW = u32 words per element (8: Fr, 2: Goldilocks); a piece is 16 bytes (Fr) or one 8-byte element
+template <int EW>
+HB_DEV int tile_pitch_words(int dp1) { return dp1 * EW + (EW >= 4 ? 4 : 2); }
 
 // stage rows [g0, g0+64) of x[G][dp1] into LDS: coalesced 16-byte pieces, wave-uniform bounds.
 // All of a lane's loads (NP = ceil(2*dp1) pieces, compile-time) are issued back-to-back BEFORE the first
 // wait, so one memory latency is exposed per tile -- a `load; s_waitcnt vmcnt(0); ds_write` loop exposed
 // twelve of them per wave (SQ_WAIT_ANY ~47 % of wave cycles, profiles/r01_pmc_compute_shares_v1.txt).
-template <int NP>
+template <int NP, int EW>
 HB_DEV void stage_tile(uint32_t* __restrict__ lds, const uint32_t* __restrict__ x, size_t g0, size_t G, int dp1,
                        int lane) {
-    const int pieces_per_row = dp1 * 2;
+    constexpr int PW = EW >= 4 ? 4 : 2;  // words per piece
+    using piece_t = typename std::conditional<PW == 4, uint4, uint2>::type;
+    const int pieces_per_row = dp1 * (EW / PW);
     const size_t rows = G - g0 < (size_t)EVAL_TILE ? G - g0 : (size_t)EVAL_TILE;
     const int total = (int)rows * pieces_per_row;
-    const uint4* src = reinterpret_cast<const uint4*>(x + g0 * (size_t)dp1 * 8);
-    const int pitch = tile_pitch_words(dp1);
+    const piece_t* src = reinterpret_cast<const piece_t*>(x + g0 * (size_t)dp1 * EW);
+    const int pitch = tile_pitch_words<EW>(dp1);
     for (int base = 0; base < total; base += NP * EVAL_TILE) {  // one trip unless dp1 > NP/2 (fold kernels)
-        uint4 v[NP];
+        piece_t v[NP];
         int pc[NP];
 #pragma unroll
         for (int it = 0; it < NP; ++it) {
@@ -173,7 +178,7 @@ HB_DEV void stage_tile(uint32_t* __restrict__ lds, const uint32_t* __restrict__ 
 #pragma unroll
         for (int it = 0; it < NP; ++it) {
             const int row = pc[it] / pieces_per_row, part = pc[it] - row * pieces_per_row;
-            *reinterpret_cast<uint4*>(lds + row * pitch + part * 4) = v[it];
+            *reinterpret_cast<piece_t*>(lds + row * pitch + part * PW) = v[it];
         }
     }
 }
@@ -184,8 +189,8 @@ template <class F, int LOG, int CNT, int P>
 HB_DEV void load_plain_one(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ row, int dp1, bool fold) {
     constexpr int k = bitrev_c(LOG, P);
     if constexpr (k < CNT) {
-        X[P] = F::load(row + k * 8);
-        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::load(row + (k + 16) * 8));
+        X[P] = F::load(row + k * F::EW);
+        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::load(row + (k + 16) * F::EW));
     }
 }
 template <class F, int LOG, int CNT, int... P>
@@ -198,8 +203,8 @@ HB_DEV void load_twisted_one(typename F::E (&X)[16], const uint32_t* __restrict_
                              const uint32_t* __restrict__ tr, int dp1, bool fold) {
     constexpr int k = bitrev_c(4, P);
     if constexpr (k < CNT) {
-        X[P] = F::mulc_u(F::load(row + k * 8), tr + k * F::NL);
-        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::mulc_u(F::load(row + (k + 16) * 8), tr + (k + 16) * F::NL));
+        X[P] = F::mulc_u(F::load(row + k * F::EW), tr + k * F::NL);
+        if (fold && k + 16 < dp1) X[P] = F::add(X[P], F::mulc_u(F::load(row + (k + 16) * F::EW), tr + (k + 16) * F::NL));
     }
 }
 template <class F, int CNT, int... P>
@@ -210,7 +215,7 @@ HB_DEV void load_twisted(typename F::E (&X)[16], const uint32_t* __restrict__ ro
 template <class F, int S, int I>
 HB_DEV void store_one(const typename F::E (&X)[S], uint32_t* __restrict__ y, size_t G, size_t g, int r, int P, int n) {
     const int j = r + P * I;
-    if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, X[I]);
+    if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, X[I]);
 }
 template <class F, int S, int... I>
 HB_DEV void store_all(const typename F::E (&X)[S], uint32_t* __restrict__ y, size_t G, size_t g, int r, int P, int n,
@@ -222,7 +227,7 @@ HB_DEV void store_all(const typename F::E (&X)[S], uint32_t* __restrict__ y, siz
 // single-pass kernel: size = 2^LOG <= 16, DP1 = CNT coefficients
 // ---------------------------------------------------------------------------------------------
 template <class F, int LOG, int CNT>
-__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, F::EVAL_WAVES))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
                                                          const uint32_t* __restrict__ tw, uint32_t* __restrict__ y) {
     using E = typename F::E;
     constexpr int S = 1 << LOG;
@@ -230,16 +235,16 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
-    stage_tile<2 * CNT>(lds, x, g0, G, CNT, lane);
+    stage_tile<CNT * (F::EW >= 4 ? 2 : 1), F::EW>(lds, x, g0, G, CNT, lane);
     __syncthreads();
     const size_t g = g0 + lane;
     if (g >= G) return;
-    const uint32_t* row = lds + lane * tile_pitch_words(CNT);
+    const uint32_t* row = lds + lane * tile_pitch_words<F::EW>(CNT);
     E X[S];
     load_plain<F, LOG, CNT>(X, row, CNT, false, std::make_integer_sequence<int, S>{});
     fft_pruned_sink<F, LOG, CNT, 1, 1>(X, tw, [&](auto idx, const E& v) {
         constexpr int j = decltype(idx)::value;
-        if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, v);
+        if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, v);
     });
 }
 
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
 // CNT16 = min(dp1, 16).  FOLD = dp1 > 16.
 // ---------------------------------------------------------------------------------------------
 template <class F, int CNT16, bool FOLD>
-__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, F::EVAL_WAVES))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
                                                          int P, const uint32_t* __restrict__ tw16,
                                                          const uint32_t* __restrict__ twist,
                                                          uint32_t* __restrict__ y) {
@@ -259,17 +264,17 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
-    stage_tile<FOLD ? 16 : 2 * CNT16>(lds, x, g0, G, dp1, lane);
+    stage_tile<(FOLD ? 8 : CNT16) * (F::EW >= 4 ? 2 : 1), F::EW>(lds, x, g0, G, dp1, lane);
     __syncthreads();
     const size_t g = g0 + lane;
     if (g >= G) return;
-    const uint32_t* row = lds + lane * tile_pitch_words(dp1);
+    const uint32_t* row = lds + lane * tile_pitch_words<F::EW>(dp1);
     {  // pass 0: no twist
         E X[16];
         load_plain<F, 4, CNT16>(X, row, dp1, FOLD, std::make_integer_sequence<int, 16>{});
         fft_pruned_sink<F, 4, CNT16, Q, Q>(X, tw16, [&](auto idx, const E& v) {
             const int j = P * decltype(idx)::value;
-            if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, v);
+            if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, v);
         });
     }
     for (int r = 1; r < P; ++r) {
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, 2)
         load_twisted<F, CNT16>(X, row, twist + (size_t)r * dp1 * F::NL, dp1, FOLD, std::make_integer_sequence<int, 16>{});
         fft_pruned_sink<F, 4, CNT16, Q, 2 * Q>(X, tw16, [&](auto idx, const E& v) {
             const int j = r + P * decltype(idx)::value;
-            if (j < n) F::store_loose(y + ((size_t)j * G + g) * 8, v);
+            if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, v);
         });
     }
 }

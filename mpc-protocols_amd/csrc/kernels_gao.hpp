@@ -12,7 +12,8 @@
 // count (:613-622).  The EEA is run FRACTION-FREE (each elimination step is
 // lead(r1)*r0 - lead(r0)*x^s*r1, applied to the t-sequence too): (g, v) come out scaled by a common
 // nonzero factor, which changes neither degrees, nor g/v, nor whether the remainder is zero -- so
-// the only field inversion per chunk is lead(v)^-1 for the final exact division.
+// the only field inversion per chunk is the one that un-scales an ACCEPTED quotient (the division itself is
+// fraction-free too, so rejected rounds never invert).
 // All LDS-resident coefficients are kept canonical (of Montgomery-form values), so "is zero" and
 // degrees are plain limb tests.
 #pragma once
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             const int dg = d1;
             const int dv = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(t1 + tid * NL)) ? -1 : tid, iscr);
             bool ok = true;
+            bool scaled = false;  // fq holds l^N * quotient, BC[1] = l^N (Montgomery form)
             int df = -1;  // degree of the quotient (-1: zero polynomial)
             uint32_t* fq = t0;  // quotient coefficients are written over t0 (no longer needed)
             if (dg < 0) {
@@ -206,32 +208,43 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             } else if (dg < dv) {
                 ok = false;  // quotient 0, remainder g != 0
             } else {
-                if (tid == 0) {
-                    const E inv = fr_inverse_mont<F>(lds_get<F>(t1 + dv * NL), a.inv_exp, a.r2, a.one_plain);
-                    lds_put<F>(BC, inv);
-                }
-                __syncthreads();
-                const E inv = lds_get<F>(BC);
+                // Fraction-free long division first: l^N g = Q' v + R' with l = lead(v), N = dg - dv + 1
+                // (each step: R <- l R - lead(R) x^sh v, Q' <- l Q' + lead(R) x^sh).  Whether the remainder is
+                // zero and the degree of the quotient do not depend on the scaling, so a round that fails here
+                // (the usual fate of an OEC round with too few points for the errors present) costs NO field
+                // inversion; only an accepted division pays for one (a single-lane Fermat chain, ~100k
+                // instructions -- it used to dominate the fallback when several rounds were needed).
+                const E l = lds_get<F>(t1 + dv * NL);
                 __syncthreads();
                 lds_put<F>(fq + tid * NL, F::zero());
                 __syncthreads();
-                // long division of r1 (in place) by t1
                 for (int top = dg; top >= dv; --top) {
                     const E lead = lds_get<F>(r1 + top * NL);
-                    const E c = F::cond_sub_r(F::mont(lead, inv));  // quotient coefficient
                     const int sh = top - dv;
-                    E nr = lds_get<F>(r1 + tid * NL);
-                    if (tid >= sh && tid <= top)
-                        nr = F::canon_loose(F::template sub<4>(nr, F::mont(lds_get<F>(t1 + (tid - sh) * NL), c)));
+                    E nr = F::mont(lds_get<F>(r1 + tid * NL), l);
+                    if (tid >= sh && tid <= top) nr = F::template sub<4>(nr, F::mont(lds_get<F>(t1 + (tid - sh) * NL), lead));
+                    nr = F::canon_loose(nr);
+                    E nq = F::mont(lds_get<F>(fq + tid * NL), l);
+                    if (tid == sh) nq = F::add(nq, lead);
+                    nq = F::canon_loose(nq);
                     __syncthreads();
                     lds_put<F>(r1 + tid * NL, nr);
-                    if (tid == sh) lds_put<F>(fq + sh * NL, c);
+                    lds_put<F>(fq + tid * NL, nq);
                     __syncthreads();
                 }
                 const int drem = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
                 if (drem >= 0) ok = false;  // remainder must be zero
                 df = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(fq + tid * NL)) ? -1 : tid, iscr);
                 if ((df < 0 ? 0 : df) >= a.k) ok = false;  // quotient.degree() < k
+                if (ok) {  // l^N, needed by the acceptance count and by the final un-scaling
+                    if (tid == 0) {
+                        E sc = l;
+                        for (int i = dv; i < dg; ++i) sc = F::cond_sub_r(F::mont(sc, l));
+                        lds_put<F>(BC + NL, sc);
+                    }
+                    scaled = true;
+                    __syncthreads();
+                }
             }
             if (ok && a.accept_min > 0) {
                 // matched = #{known j : f(alpha_j) == y_j} >= d+t+1 (:613-620)
@@ -244,7 +257,9 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                         acc = F::add(acc, lds_get<F>(fq + kx * NL));
                     }
                     const E val = F::cond_sub_r(F::mont(F::canon_loose(acc), a.one_plain));  // leave Montgomery form
-                    const E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.row_stride + g) * F::EW);
+                    E ys = F::load(a.evals + ((size_t)a.rows[tid] * a.row_stride + g) * F::EW);
+                    // compare l^N f(alpha_j) with l^N y_j: still no inversion for a round that is not accepted
+                    if (scaled) ys = F::cond_sub_r(F::mont(ys, lds_get<F>(BC + NL)));
                     hit = F::eq_canon(val, ys) ? 1 : 0;
                 }
                 // block-wide sum via max of prefix counts is overkill: use LDS atomics
@@ -254,6 +269,15 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 if (hit) atomicAdd(&iscr[8], 1);
                 __syncthreads();
                 if (iscr[8] < a.accept_min) ok = false;
+                __syncthreads();
+            }
+            if (ok && scaled) {  // accepted: Q = Q' / l^N, the one inversion of this chunk
+                if (tid == 0) lds_put<F>(BC, fr_inverse_mont<F>(lds_get<F>(BC + NL), a.inv_exp, a.r2, a.one_plain));
+                __syncthreads();
+                const E inv = lds_get<F>(BC);
+                const E q = F::cond_sub_r(F::mont(lds_get<F>(fq + tid * NL), inv));
+                __syncthreads();
+                lds_put<F>(fq + tid * NL, q);
                 __syncthreads();
             }
             if (ok) {

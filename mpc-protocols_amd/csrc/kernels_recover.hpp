@@ -105,11 +105,11 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     const size_t gg = live ? g : a.G - 1;
     E y[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * 8);
+    for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * F::EW);
     bool ok = true;
     for (int s = M; s < a.needed; ++s) {
         const E p = F::cond_sub_r(dot_row<F, M>(y, a.vm + (size_t)(s - M) * M * F::NL));
-        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * 8);
+        const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * F::EW);
         ok = ok && F::eq_canon(p, ys);
     }
     flag_chunks<F>(live && !ok, g, a);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     if (!ok) return;
     constexpr int OW = P0_ONLY ? 1 : M;
     for (int k = 0; k < OW; ++k)
-        F::store_lt2r(a.out + (g * OW + k) * 8, dot_row<F, M>(y, a.bc + (size_t)k * M * F::NL));
+        F::store_lt2r(a.out + (g * OW + k) * F::EW, dot_row<F, M>(y, a.bc + (size_t)k * M * F::NL));
     if (a.ncoeffs) a.ncoeffs[g] = M;
 }
 

@@ -28,6 +28,11 @@ bool launch_fftP_d(int dp1, const uint32_t* x, size_t G, int n, int P, const uin
                    uint32_t* y, hipStream_t s);
 bool launch_fftP_fold(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
                       uint32_t* y, hipStream_t s);
+// Goldilocks instantiations of the same templates
+bool launch_gold_fft1(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_gold_fftP(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
+                      uint32_t* y, hipStream_t s);
+bool launch_gold_recover(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 // generic Horner evaluation (impl: 0 = U29, 1 = Sat32, 2 = Goldilocks)
 void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y,
                          hipStream_t s);

@@ -83,11 +83,12 @@ inline std::vector<H> domain_elements(size_t n, size_t count) {
 }
 
 // tw[q] = omega_S^q, q < max(S/2, 1)
+template <class H = HFr>
 inline std::vector<uint32_t> build_twiddles(size_t S, int impl) {
     std::vector<uint32_t> out;
-    HFr w;
+    H w;
     domain_omega(S, &w);
-    HFr p = HFr::one();
+    H p = H::one();
     for (size_t q = 0; q < std::max<size_t>(S / 2, 1); ++q) {
         put_const(out, p, impl);
         p = p * w;
@@ -95,13 +96,14 @@ inline std::vector<uint32_t> build_twiddles(size_t S, int impl) {
     return out;
 }
 // twist[r][k] = omega_size^(r k), r < P, k < dp1
+template <class H = HFr>
 inline std::vector<uint32_t> build_twist(size_t size, size_t P, size_t dp1, int impl) {
     std::vector<uint32_t> out;
-    HFr w;
+    H w;
     domain_omega(size, &w);
-    HFr wr = HFr::one();
+    H wr = H::one();
     for (size_t r = 0; r < P; ++r) {
-        HFr p = HFr::one();
+        H p = H::one();
         for (size_t k = 0; k < dp1; ++k) {
             put_const(out, p, impl);
             p = p * wr;

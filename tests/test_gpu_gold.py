@@ -17,10 +17,19 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def eng():
+def _eng():
     e = load_package().Engine(0, field="goldilocks")
     yield e
     e.close()
+
+
+@pytest.fixture(params=["fast", "generic"])
+def eng(request, _eng):
+    """fast: the pruned-FFT / register-resident kernels instantiated for Goldilocks; generic: the runtime-shaped
+    Horner / re-reading kernels (what shapes outside the templates fall back to)"""
+    _eng.set_force_generic(request.param == "generic")
+    yield _eng
+    _eng.set_force_generic(False)
 
 
 def rnd(seed, *shape):
@@ -233,6 +242,10 @@ def test_full_size_roundtrip_and_linearity(eng):
     encode -> erase t senders -> decode round trip; linearity checksum; strided decode of a sub-range."""
     import torch
     dev = torch.device("cuda", 0)
+    # an explicit torch stream whose handle goes through the C ABI: torch's work and the library's kernels are then
+    # ordered on ONE stream (handle 0 would mean "the context's own stream", unordered with torch's default stream)
+    ts = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(ts)
     n, t, d, G = 16, 5, 5, 1 << 20
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
@@ -240,7 +253,8 @@ def test_full_size_roundtrip_and_linearity(eng):
     lo = torch.randint(0, 1 << 32, (G, d + 1), dtype=torch.int64, device=dev, generator=g)
     x = (hi << 32) | lo
     y = torch.empty((n, G), dtype=torch.int64, device=dev)
-    s = torch.cuda.current_stream().cuda_stream
+    s = ts.cuda_stream
+    assert s != 0
     assert eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), s) == 0
     keep = [15, 3, 8, 0, 12, 5, 9, 1, 14, 7, 2]            # d + t + 1 = 11 of the 16 senders, arrival order
     ysub = y[keep].contiguous()
@@ -274,3 +288,4 @@ def test_full_size_roundtrip_and_linearity(eng):
     torch.cuda.synchronize()
     assert bool((sec == x[:, 0]).all()) and summ.tolist()[:2] == [G // 64, 0]
     assert int(st[::64].min()) == 1 and int(st[1::64].max()) == 0
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
