@@ -29,6 +29,8 @@ struct hbmpc_ctx {
     std::map<std::string, uint32_t*> tables;       // device-resident constant tables
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
     std::map<hipStream_t, std::pair<void*, size_t>> scratch;  // per-stream scratch (calls on one stream are ordered)
+    std::vector<std::pair<void*, size_t>> stage_free;  // device staging buffers of the host-pointer API, kept between calls
+    size_t stage_bytes = 0;
     std::string err;
 };
 
@@ -166,6 +168,7 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second);
     for (auto& kv : ctx->scratch) (void)hipFree(kv.second.first);
+    for (auto& b : ctx->stage_free) (void)hipFree(b.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -296,13 +299,45 @@ extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const u
     return eval_dev(ctx, x, G, n, d, y_out, stream);
 }
 
-// host wrapper helper: RAII device buffers on the ctx stream
+// host wrapper helper: RAII device staging buffers for the host-pointer API.  They are recycled through a small
+// per-context pool: hipMalloc + hipFree (which synchronises the device) cost ~0.45 ms per call, half the time of
+// a 2^14-secret hbmpc_compute_shares.  Every user of a buffer runs on the context's own stream, so a recycled
+// buffer is ordered behind its previous use.
 struct DevBuf {
     void* p = nullptr;
+    size_t cap = 0;
+    hbmpc_ctx* owner = nullptr;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(owner->mu);
+        if (owner->stage_free.size() < 16 && owner->stage_bytes + cap <= ((size_t)2 << 30)) {
+            owner->stage_free.emplace_back(p, cap);
+            owner->stage_bytes += cap;
+        } else {
+            (void)hipFree(p);
+        }
     }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    hipError_t alloc(hbmpc_ctx* ctx, size_t bytes) {
+        owner = ctx;
+        if (bytes == 0) bytes = 1;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            int best = -1;
+            for (int i = 0; i < (int)ctx->stage_free.size(); ++i) {
+                const size_t c = ctx->stage_free[i].second;
+                if (c >= bytes && c <= 4 * bytes + (1u << 20) && (best < 0 || c < ctx->stage_free[best].second)) best = i;
+            }
+            if (best >= 0) {
+                p = ctx->stage_free[best].first;
+                cap = ctx->stage_free[best].second;
+                ctx->stage_bytes -= cap;
+                ctx->stage_free.erase(ctx->stage_free.begin() + best);
+                return hipSuccess;
+            }
+        }
+        cap = bytes < (1u << 16) ? (1u << 16) : bytes + bytes / 4;
+        return hipMalloc(&p, cap);
+    }
 };
 
 static ShareErrorCode eval_host(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y) {
@@ -313,8 +348,8 @@ static ShareErrorCode eval_host(hbmpc_ctx* ctx, const void* x, size_t G, size_t 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     DevBuf dx, dy;
     const size_t eb = ebytes(ctx);
-    HIP_TRY(ctx, dx.alloc(G * (d + 1) * eb));
-    HIP_TRY(ctx, dy.alloc(G * n * eb));
+    HIP_TRY(ctx, dx.alloc(ctx, G * (d + 1) * eb));
+    HIP_TRY(ctx, dy.alloc(ctx, G * n * eb));
     HIP_TRY(ctx, hipMemcpyAsync(dx.p, x, G * (d + 1) * eb, hipMemcpyHostToDevice, ctx->stream));
     ShareErrorCode rc = eval_dev(ctx, dx.p, G, n, d, dy.p, nullptr);
     if (rc != ShareSuccess) return rc;
@@ -537,7 +572,7 @@ static ShareErrorCode elem_host(hbmpc_ctx* ctx, std::initializer_list<std::pair<
     size_t k = 0;
     for (auto& in : ins) {
         if (in.second && !in.first) return fail(ctx, InvalidInput, "null buffer");
-        HIP_TRY(ctx, bi[k].alloc(in.second * eb));
+        HIP_TRY(ctx, bi[k].alloc(ctx, in.second * eb));
         HIP_TRY(ctx, hipMemcpyAsync(bi[k].p, in.first, in.second * eb, hipMemcpyHostToDevice, ctx->stream));
         pi.push_back(bi[k].p);
         ++k;
@@ -545,7 +580,7 @@ static ShareErrorCode elem_host(hbmpc_ctx* ctx, std::initializer_list<std::pair<
     k = 0;
     for (auto& o : outs) {
         if (o.second && !o.first) return fail(ctx, InvalidInput, "null buffer");
-        HIP_TRY(ctx, bo[k].alloc(o.second * eb));
+        HIP_TRY(ctx, bo[k].alloc(ctx, o.second * eb));
         po.push_back(bo[k].p);
         ++k;
     }
