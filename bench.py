@@ -194,6 +194,12 @@ def main():
             out["extra"] = extra_measurements(eng, torch, dev, stream, cref)
             # the second half of BASELINE.json's metric, for convenience at the top level
             out["recons_per_s"] = out["extra"]["cfg3_decode"]["recons_per_s"]
+            # context for `frac` (report against the vendor peak AND what the chip delivers): a plain
+            # device copy measured in this run, and the no-arithmetic kernel with exactly this kernel's traffic
+            # (27 % reads / 73 % writes, tools/ubench_store.hip, profiles/r01_store_pattern_ubench.txt)
+            out["roofline"]["peak_measured_copy_GBps"] = out["extra"]["device_copy_GBps"]
+            out["roofline"]["same_traffic_no_arithmetic_GBps"] = 4900.0
+            out["roofline"]["frac_of_same_traffic_floor"] = achieved / 4900.0
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -19,7 +19,8 @@ namespace hbmpc {
 struct Gold {
     static constexpr int NL = 2;  // words per constant
     static constexpr int EW = 2;  // words per stored element
-    static constexpr int EVAL_WAVES = 8;  // memory-bound: as many waves as fit
+    template <int LOG, int CNT>
+    static constexpr int eval_waves() { return 8; }  // memory-bound: as many waves as fit
     static constexpr int MAX_DOT_TERMS = 1 << 30;
     static constexpr uint64_t P = 0xFFFFFFFF00000001ull;
     static constexpr uint64_t EPS = 0xFFFFFFFFull;

@@ -17,7 +17,8 @@ namespace hbmpc {
 struct Sat32 {
     static constexpr int NL = 8;
     static constexpr int EW = 8;  // u32 words per stored element
-    static constexpr int EVAL_WAVES = 2;
+    template <int LOG, int CNT>
+    static constexpr int eval_waves() { return 2; }
     static constexpr int MAX_DOT_TERMS = 1 << 30;
 
     struct E {

@@ -37,7 +37,11 @@ struct U29 {
     // A 64-bit column holds 2^64 / 2^58 = 64 products of normalised limbs.  A term adds up to 9 per column,
     // the reduction up to 8 more (m * r) plus carries: 9 T + 9 <= 64  =>  T <= 6 terms between folds.
     static constexpr int EW = 8;  // u32 words per stored element
-    static constexpr int EVAL_WAVES = 2;  // waves per SIMD the register-resident FFT kernels are compiled for
+    // waves per SIMD the register-resident FFT kernels are compiled for: with <= 6 non-zero inputs the inputs of
+    // the second-to-last stage are <= 8 distinct values and the interleaved last two stages (kernels_eval.hpp)
+    // fit 168 VGPRs; with more inputs all 16 values are live and the kernel stays at 2 waves.
+    template <int LOG, int CNT>
+    static constexpr int eval_waves() { return (LOG < 4 || CNT <= 6) ? 3 : 2; }
     static constexpr int MAX_DOT_TERMS = 6;
 
     struct E {

@@ -115,20 +115,40 @@ HB_DEV void fft_pruned(typename F::E (&X)[1 << LOG], const uint32_t* __restrict_
 // the stores of a tile are spread over the last stage's multiplies instead of bunched behind the arithmetic
 // -- the kernel's traffic alone needs ~150 us per 2^20 secrets (profiles/r01_store_pattern_ubench.txt), as
 // long as the arithmetic, so the two have to overlap.
-template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink, int... IDX>
-HB_DEV void fft_last_stage_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink,
-                                std::integer_sequence<int, IDX...>) {
-    ((fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 1, IDX>(X, tw), sink(std::integral_constant<int, IDX>{}, X[IDX]),
-      sink(std::integral_constant<int, IDX + (1 << (LOG - 1))>{}, X[IDX + (1 << (LOG - 1))])),
-     ...);
+// The last TWO stages are walked together, quarter by quarter: for k < S/4 the two stage-(LOG-2) butterflies
+// that produce X[k], X[k+S/4], X[S/2+k], X[S/2+k+S/4] are immediately followed by the two last-stage
+// butterflies that consume exactly those four values and hand the four finished outputs to the sink.  Same
+// butterflies, same results -- but the 16 values of the last stage's input never exist at once: live data
+// peaks at the 8 inputs of stage LOG-2 plus the quarter in flight (108 + 36 registers instead of 144 + ...),
+// which is what lets these kernels run at 3 waves per SIMD.
+template <class F, int LOG, int CNT, int LBU0, int VB0, int K, class Sink>
+HB_DEV void fft_last_two_quarter(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink) {
+    constexpr int S = 1 << LOG, Q = S / 4, H = S / 2;
+    fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 2, K>(X, tw);
+    fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 2, Q + K>(X, tw);
+    fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 1, K>(X, tw);
+    sink(std::integral_constant<int, K>{}, X[K]);
+    sink(std::integral_constant<int, K + H>{}, X[K + H]);
+    fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 1, K + Q>(X, tw);
+    sink(std::integral_constant<int, K + Q>{}, X[K + Q]);
+    sink(std::integral_constant<int, K + Q + H>{}, X[K + Q + H]);
+}
+template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink, int... K>
+HB_DEV void fft_last_two_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink,
+                              std::integer_sequence<int, K...>) {
+    (fft_last_two_quarter<F, LOG, CNT, LBU0, VB0, K>(X, tw, sink), ...);
 }
 template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink>
 HB_DEV void fft_pruned_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink) {
     if constexpr (LOG == 0) {
         sink(std::integral_constant<int, 0>{}, X[0]);
+    } else if constexpr (LOG == 1) {
+        fft_bfly<F, 1, CNT, LBU0, VB0, 0, 0>(X, tw);
+        sink(std::integral_constant<int, 0>{}, X[0]);
+        sink(std::integral_constant<int, 1>{}, X[1]);
     } else {
-        if constexpr (LOG > 1) fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG - 1>{});
-        fft_last_stage_sink<F, LOG, CNT, LBU0, VB0>(X, tw, sink, std::make_integer_sequence<int, (1 << LOG) / 2>{});
+        if constexpr (LOG > 2) fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG - 2>{});
+        fft_last_two_sink<F, LOG, CNT, LBU0, VB0>(X, tw, sink, std::make_integer_sequence<int, (1 << LOG) / 4>{});
     }
 }
 template <int LOG, int CNT, int LBU0, int VB0>
@@ -227,7 +247,7 @@ HB_DEV void store_all(const typename F::E (&X)[S], uint32_t* __restrict__ y, siz
 // single-pass kernel: size = 2^LOG <= 16, DP1 = CNT coefficients
 // ---------------------------------------------------------------------------------------------
 template <class F, int LOG, int CNT>
-__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, F::EVAL_WAVES))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves<LOG, CNT>(), F::template eval_waves<LOG, CNT>()))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
                                                          const uint32_t* __restrict__ tw, uint32_t* __restrict__ y) {
     using E = typename F::E;
     constexpr int S = 1 << LOG;
@@ -254,7 +274,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, F:
 // CNT16 = min(dp1, 16).  FOLD = dp1 > 16.
 // ---------------------------------------------------------------------------------------------
 template <class F, int CNT16, bool FOLD>
-__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(1, F::EVAL_WAVES))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves<4, CNT16 + (FOLD ? 16 : 0)>(), F::template eval_waves<4, CNT16 + (FOLD ? 16 : 0)>()))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
                                                          int P, const uint32_t* __restrict__ tw16,
                                                          const uint32_t* __restrict__ twist,
                                                          uint32_t* __restrict__ y) {
