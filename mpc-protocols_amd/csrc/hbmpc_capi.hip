@@ -25,7 +25,8 @@ struct hbmpc_ctx {
     int impl = IMPL_U29;
     bool force_generic = false;                    // tests: route every shape through the generic kernels
     hipStream_t stream = nullptr;
-    std::mutex mu;                                 // serialises host-API calls and the table cache
+    std::mutex mu;                                 // guards the table cache, the scratch map and the staging pool
+    std::mutex enqueue_mu;                         // keeps multi-launch sequences that share scratch contiguous on a stream
     std::map<std::string, uint32_t*> tables;       // device-resident constant tables
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
     std::map<hipStream_t, std::pair<void*, size_t>> scratch;  // per-stream scratch (calls on one stream are ordered)

@@ -375,3 +375,31 @@ def test_interpolate_headroom_adversarial(eng):
     ids = list(range(S))
     rc, co, deg = eng.batch_interpolate(ids, np.ascontiguousarray(y[:S]), n)
     assert rc == 0 and GU.eq(co[:, 0], x[:, 0]) and not co[:, 1:].any() and not deg.any()
+
+
+def test_one_context_many_threads(eng):
+    """include/hbmpc_hip.h: 'thread-safe and re-entrant: calls on one ctx from several threads serialise on the
+    ctx's stream'.  Four threads hammer ONE context with encode + corrupted decode (every chunk takes the
+    flag -> OEC/Gao path, whose two kernels share per-stream scratch) and must all get exact results."""
+    import threading
+    n, t, d, G = 10, 3, 3, 64
+    errs = []
+
+    def worker(seed):
+        try:
+            x = rnd(1000 + seed, G, d + 1)
+            for it in range(25):
+                rc, y = eng.vandermonde_apply(x, n, d)
+                assert rc == 0
+                y[seed % n, :, 0] ^= np.uint64(1)            # one corrupted sender: every chunk falls back
+                rc, co, nco, st = eng.batch_recover(list(range(n)), y, n, d, t)
+                assert rc == 0 and np.array_equal(co, x) and (st == 1).all() and (nco == d + 1).all(), (seed, it)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for q in th:
+        q.start()
+    for q in th:
+        q.join()
+    assert not errs, errs[:2]
