@@ -32,22 +32,25 @@ struct hbmpc_ctx {
     std::map<hipStream_t, std::pair<void*, size_t>> scratch;  // per-stream scratch (calls on one stream are ordered)
     std::vector<std::pair<void*, size_t>> stage_free;  // device staging buffers of the host-pointer API, kept between calls
     size_t stage_bytes = 0;
-    std::string err;
 };
 
+// the calling thread's last failure message (hbmpc_last_error): thread-local, so concurrent callers of one
+// context never write the same string
 static thread_local std::string g_err;
 
 #define HIP_TRY(ctx, call)                                                                              \
     do {                                                                                                \
         hipError_t e__ = (call);                                                                        \
         if (e__ != hipSuccess) {                                                                        \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                            \
+            (void)(ctx);                                                                                \
+            g_err = std::string(#call) + ": " + hipGetErrorString(e__);                            \
             return e__ == hipErrorOutOfMemory ? HBMPC_OUT_OF_MEMORY : HBMPC_NO_DEVICE;                  \
         }                                                                                               \
     } while (0)
 
 static ShareErrorCode fail(hbmpc_ctx* ctx, ShareErrorCode rc, const char* msg) {
-    if (ctx) ctx->err = msg;
+    (void)ctx;
+    g_err = msg;
     return rc;
 }
 
@@ -173,7 +176,7 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
-extern "C" const char* hbmpc_last_error(const hbmpc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+extern "C" const char* hbmpc_last_error(const hbmpc_ctx*) { return g_err.c_str(); }
 extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
     REQ_FR(ctx);
