@@ -1,0 +1,106 @@
+"""Randomised shape sweep (fixed seeds): random (n, t, d), random subsets and arrival orders of senders, random
+corruption patterns, both fields -- every result compared with the big-int oracle (oracle/spec.py,
+oracle/spec_gl.py), error codes included.  Complements the hand-picked shapes of test_gpu_parity.py /
+test_gpu_gold.py: the kernels are dispatched by shape (pruned-FFT sizes, register-resident m <= 16, generic
+fall-backs, OEC/Gao block sizes 64/128/256), so a sweep walks the dispatch boundaries."""
+import random
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import spec as SFR
+from oracle.spec_gl import S as SGL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engines():
+    pkg = load_package()
+    e = {"fr": pkg.Engine(0), "goldilocks": pkg.Engine(0, field="goldilocks")}
+    yield e
+    for v in e.values():
+        v.close()
+
+
+def to_arr(field, rows):  # rows: nested lists of python ints
+    a = np.array(rows, dtype=object)
+    if field == "goldilocks":
+        return a.astype(np.uint64)
+    out = np.zeros(a.shape + (4,), dtype=np.uint64)
+    for idx in np.ndindex(a.shape):
+        v = int(a[idx])
+        out[idx] = [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)]
+    return out
+
+
+def to_int(field, x):
+    if field == "goldilocks":
+        return int(x)
+    return sum(int(x[k]) << (64 * k) for k in range(4))
+
+
+def rand_shape(rng):
+    kind = rng.randrange(5)
+    if kind == 0:
+        n = rng.randint(4, 16)
+    elif kind == 1:
+        n = rng.randint(17, 40)
+    elif kind == 2:
+        n = rng.choice([63, 64, 65, 100, 127, 128, 129])
+    elif kind == 3:
+        n = rng.choice([200, 255])
+    else:
+        n = rng.randint(4, 70)
+    t = rng.randint(1, (n - 1) // 3)
+    d = rng.choice([t, min(2 * t, n - t - 1), rng.randint(0, n - t - 1)])
+    return n, t, d
+
+
+@pytest.mark.parametrize("field", ["fr", "goldilocks"])
+@pytest.mark.parametrize("seed", range(24))
+def test_random_encode_decode(engines, field, seed):
+    eng, S = engines[field], (SFR if field == "fr" else SGL)
+    P = S.R_MOD
+    rng = random.Random(seed * 7919 + (1 if field == "fr" else 2))
+    n, t, d = rand_shape(rng)
+    G = rng.choice([1, 2, 3]) if n > 100 else rng.choice([1, 3, 17, 40])
+    polys = [[rng.randrange(P) for _ in range(d + 1)] for _ in range(G)]
+    for p in polys[:2]:                                       # low-degree / zero polynomials among them
+        for k in range(rng.randint(0, d + 1)):
+            p[d - k] = 0
+    rc, y = eng.vandermonde_apply(to_arr(field, polys), n, d)
+    assert rc == 0
+    for g in range(min(G, 3)):
+        want = [s.v for s in S.compute_shares(polys[g], n, d)] if n > d else None
+        assert [to_int(field, y[j, g]) for j in range(n)] == want
+    # a random set of senders in random arrival order, possibly too few
+    S_cnt = rng.choice([n, rng.randint(d + t + 1, n), rng.randint(max(1, d + t - 1), n)])
+    ids = rng.sample(range(n), S_cnt)
+    ev = {i: [to_int(field, y[i, g]) for g in range(G)] for i in ids}
+    # random corruption: none / <= t / more than t.  The big-int oracle pays one O(n^3) OEC round per error
+    # (3.5 s per round at n = 255), so large n gets at most two errors per chunk.
+    kmax = t if n <= 40 else min(t, 2)
+    for g in range(G):
+        mode = rng.randrange(4)
+        k = 0 if mode == 0 else (rng.randint(1, kmax) if (mode < 3 or n > 40) else rng.randint(t + 1, min(S_cnt, 2 * t + 2)))
+        for i in rng.sample(ids, min(k, S_cnt)):
+            ev[i][g] = (ev[i][g] + rng.randrange(1, P)) % P
+    rc, co, nco, st = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
+    if S_cnt < d + t + 1:                                     # robust_interpolate.rs:333-341: "Not enough evaluations"
+        with pytest.raises(S.InvalidInput):
+            S.batch_recover_secret([(i, ev[i][:1]) for i in ids], n, d, t)
+        assert rc == 4
+        return
+    any_fail = False
+    for g in range(G):
+        shares = [S.Share(ev[i][g], i, d) for i in ids]
+        try:
+            want, _ = S.recover_secret(shares, n, t)
+            got = [to_int(field, c) for c in (co[g][: nco[g]] if st[g] == 1 else co[g])]
+            assert st[g] in (0, 1) and got == want + [0] * (len(got) - len(want)), (n, t, d, g)
+        except S.ShareErr as e:
+            any_fail = True
+            assert st[g] == e.code, (n, t, d, g, st[g], e.code)
+    assert (rc != 0) == any_fail
