@@ -50,6 +50,8 @@ struct GaoArgs {
     const uint32_t* one_plain; // limbs of the integer 1 (mont(x, 1) leaves Montgomery form)
     const uint32_t* r2;        // device-constant form of R (mont(x, r2) = x*R)
     const uint32_t* inv_exp;   // r - 2 as 8 x u32
+    uint32_t* scales;          // [count][NL + 1]: word 0 = 1 when the chunk's output still carries the factor l^N held in
+                               // words 1..NL (Montgomery form); k_unscale divides it out with a batched inversion
 };
 
 template <int BLOCK>
@@ -271,21 +273,23 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 if (iscr[8] < a.accept_min) ok = false;
                 __syncthreads();
             }
-            if (ok && scaled) {  // accepted: Q = Q' / l^N, the one inversion of this chunk
-                if (tid == 0) lds_put<F>(BC, fr_inverse_mont<F>(lds_get<F>(BC + NL), a.inv_exp, a.r2, a.one_plain));
-                __syncthreads();
-                const E inv = lds_get<F>(BC);
-                const E q = F::cond_sub_r(F::mont(lds_get<F>(fq + tid * NL), inv));
-                __syncthreads();
-                lds_put<F>(fq + tid * NL, q);
-                __syncthreads();
-            }
             if (ok) {
-                // write the coefficients (canonical), zero padded to out_width
+                // Write the coefficients, zero padded to out_width.  An accepted division leaves Q' = l^N Q: the
+                // Montgomery-form residues of Q' go out as they are together with l^N, and k_unscale finishes
+                // them -- ONE Fermat inversion per eight chunks there (Montgomery's batching trick) instead of
+                // one single-lane, ~100k-instruction inversion per chunk here, which dominated the fallback.
                 if (tid < a.out_width) {
                     E c = F::zero();
-                    if (tid <= df) c = F::cond_sub_r(F::mont(lds_get<F>(fq + tid * NL), a.one_plain));
+                    if (tid <= df) {
+                        c = lds_get<F>(fq + tid * NL);
+                        if (!scaled) c = F::cond_sub_r(F::mont(c, a.one_plain));
+                    }
                     F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * F::EW, c);
+                }
+                if (tid == 0) {
+                    uint32_t* sc = a.scales + fi * (size_t)(NL + 1);
+                    sc[0] = scaled ? 1u : 0u;
+                    if (scaled) lds_put<F>(sc + 1, lds_get<F>(BC + NL));
                 }
                 out_len = df + 1;
                 result = ShareSuccess;
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * F::EW, F::zero());
         }
         if (tid == 0) {
+            if (result != ShareSuccess) a.scales[fi * (size_t)(NL + 1)] = 0u;
             if (a.ncoeffs) a.ncoeffs[g] = result == ShareSuccess ? (uint32_t)out_len : 0u;
             if (a.status) a.status[g] = result == ShareSuccess ? 1 : (uint8_t)result;
             if (a.summary) {
@@ -308,6 +313,49 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             }
         }
         __syncthreads();
+    }
+}
+
+// Second half of the fallback: divide the factor l^N out of the chunks k_gao marked.  One lane takes eight
+// consecutive entries of the flagged list, multiplies their factors together, inverts the product once
+// (Fermat) and peels the individual inverses off again (Montgomery's trick: 3 multiplications per entry).
+template <class F>
+__global__ __launch_bounds__(64) void k_unscale(GaoArgs a) {
+    using E = typename F::E;
+    constexpr int NL = F::NL, B = 8;
+    const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
+    const size_t f0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * B;
+    if (f0 >= count) return;
+    E one = F::cond_sub_r(F::mulc(F::load_const(a.one_plain), a.r2));  // 1 in Montgomery form
+    E sc[B], pre[B];
+    bool pend[B];
+    E run = one;
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+        const size_t fi = f0 + i;
+        pend[i] = fi < count && a.scales[fi * (size_t)(NL + 1)] != 0u;
+        sc[i] = one;
+        if (pend[i]) sc[i] = lds_get<F>(a.scales + fi * (size_t)(NL + 1) + 1);
+        pre[i] = run;                                   // product of the factors before entry i
+        run = F::cond_sub_r(F::mont(run, sc[i]));
+    }
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < B; ++i) any = any || pend[i];
+    if (!any) return;
+    E inv = fr_inverse_mont<F>(run, a.inv_exp, a.r2, a.one_plain);  // (prod sc)^-1
+#pragma unroll
+    for (int i = B - 1; i >= 0; --i) {
+        const E inv_i = F::cond_sub_r(F::mont(inv, pre[i]));        // sc_i^-1
+        inv = F::cond_sub_r(F::mont(inv, sc[i]));
+        if (!pend[i]) continue;
+        const size_t fi = f0 + i;
+        const size_t g = a.flagged ? (size_t)a.flagged[fi] : fi;
+        for (int k = 0; k < a.out_width; ++k) {
+            uint32_t* p = a.out + (g * (size_t)a.out_width + k) * F::EW;
+            const E q = F::cond_sub_r(F::mont(F::load(p), inv_i));             // Q'_k / l^N, Montgomery form
+            F::store_lt2r(p, F::cond_sub_r(F::mont(q, a.one_plain)));          // leave Montgomery form
+        }
     }
 }
 

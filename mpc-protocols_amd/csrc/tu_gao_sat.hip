@@ -12,5 +12,8 @@ void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s) {
         const size_t lds = (size_t)(4 * 256 + 4) * F::NL * 4 + 64;
         hipLaunchKernelGGL((k_gao<F, 256>), dim3(grid), dim3(256), lds, s, ga);
     }
+    // un-scale the accepted quotients: one lane per eight flagged chunks
+    const size_t lanes = (ga.G + 7) / 8;
+    hipLaunchKernelGGL((k_unscale<F>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, ga);
 }
 }
