@@ -346,6 +346,34 @@ def _share_on_device(eng, torch, dev, stream, secrets, n, d, out_ptr):
     torch.cuda.synchronize()
 
 
+def setup_fpmul(eng, torch, dev, stream, n, t, N, k, m):
+    """an FpMul pipeline object whose device buffers hold VALID degree-t sharings (small fixed-point inputs, a Beaver
+    triple, TruncPr's random bits and r_int), produced by the compute_shares kernel itself"""
+    from __graft_entry__ import load_package
+    fp = load_package().pipelines.FpMul(eng, n, t, N, k, m, stream)
+    x = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    y = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    x[:, 0] = torch.randint(0, 1 << 7, (N,), device=dev)
+    y[:, 0] = torch.randint(0, 1 << 7, (N,), device=dev)
+    ta, tb = _rand_fr(torch, dev, N), _rand_fr(torch, dev, N)
+    tc = torch.empty_like(ta)
+    torch.cuda.synchronize()
+    assert eng.dev_fr_op("mul", ta.data_ptr(), tb.data_ptr(), N, tc.data_ptr(), stream) == 0
+    rint = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+    rint[:, 0] = torch.randint(0, 1 << 40, (N,), device=dev)
+    for sec, ptr in ((x, fp.x), (y, fp.y), (ta, fp.ta), (tb, fp.tb), (tc, fp.tc), (rint, fp.rint)):
+        _share_on_device(eng, torch, dev, stream, sec, n, t, ptr)
+    tmp = torch.empty((n, N, 4), dtype=torch.int64, device=dev)
+    for j in range(m):  # r_bits[party][bit][N]
+        bit = torch.zeros((N, 4), dtype=torch.int64, device=dev)
+        bit[:, 0] = torch.randint(0, 2, (N,), device=dev)
+        _share_on_device(eng, torch, dev, stream, bit, n, t, tmp.data_ptr())
+        for p in range(n):
+            eng.d2d(fp.rbits + (p * m + j) * N * 32, tmp.data_ptr() + p * N * 32, N * 32, stream)
+    torch.cuda.synchronize()
+    return fp
+
+
 def pipeline_measurements(eng, torch, dev, stream, ev_time):
     """BASELINE configs 4 and 5 as device-resident replays of all n parties on ONE GPU (mpc-protocols_amd/pipelines.py)."""
     from __graft_entry__ import load_package
@@ -368,28 +396,21 @@ def pipeline_measurements(eng, torch, dev, stream, ev_time):
     del a, b, r
     # config 5: fpmul, n=16, t=5, 2^18 elements, (k, f) = (16, 4)
     N, k, m = 1 << 18, 16, 4
-    fp = pl.FpMul(eng, n, t, N, k, m, stream)
-    x = torch.zeros((N, 4), dtype=torch.int64, device=dev)
-    y = torch.zeros((N, 4), dtype=torch.int64, device=dev)
-    x[:, 0] = torch.randint(0, 1 << 7, (N,), device=dev)
-    y[:, 0] = torch.randint(0, 1 << 7, (N,), device=dev)
-    ta, tb = _rand_fr(torch, dev, N), _rand_fr(torch, dev, N)
-    tc = torch.empty_like(ta)
-    assert eng.dev_fr_op("mul", ta.data_ptr(), tb.data_ptr(), N, tc.data_ptr(), stream) == 0
-    rint = torch.zeros((N, 4), dtype=torch.int64, device=dev)
-    rint[:, 0] = torch.randint(0, 1 << 40, (N,), device=dev)
-    for sec, ptr in ((x, fp.x), (y, fp.y), (ta, fp.ta), (tb, fp.tb), (tc, fp.tc), (rint, fp.rint)):
-        _share_on_device(eng, torch, dev, stream, sec, n, t, ptr)
-    tmp = torch.empty((n, N, 4), dtype=torch.int64, device=dev)
-    for j in range(m):  # r_bits[party][bit][N]
-        bit = torch.zeros((N, 4), dtype=torch.int64, device=dev)
-        bit[:, 0] = torch.randint(0, 2, (N,), device=dev)
-        _share_on_device(eng, torch, dev, stream, bit, n, t, tmp.data_ptr())
-        for p in range(n):
-            eng.d2d(fp.rbits + (p * m + j) * N * 32, tmp.data_ptr() + p * N * 32, N * 32, stream)
+    fp = setup_fpmul(eng, torch, dev, stream, n, t, N, k, m)
     torch.cuda.synchronize()
     ms = ev_time(fp.run, reps=3, warm=1)
     res["cfg5_fpmul_16_parties"] = {"fpmuls_per_s": N / ms * 1e3, "ms": ms, "elements": N, "k": k, "f": m}
+    fp.close()
+    # the regime the protocols actually run in: small batches, where the ~110 launches of one fpmul are launch-bound.
+    # Eager hbmpc_dev_* calls vs the same sequence captured once into a HIP graph (hbmpc_graph_*) and replayed.
+    Ns = 1024
+    fp = setup_fpmul(eng, torch, dev, stream, n, t, Ns, k, m)
+    fp.run(check=True)
+    ms_eager = ev_time(lambda: fp.run(check=False), reps=20, warm=2)
+    fp.capture()
+    ms_graph = ev_time(fp.replay, reps=20, warm=2)
+    res["cfg5_fpmul_small_batch"] = {"elements": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
+                                     "fpmuls_per_s_hip_graph": Ns / ms_graph * 1e3}
     fp.close()
     return res
 

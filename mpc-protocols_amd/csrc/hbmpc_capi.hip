@@ -222,6 +222,45 @@ extern "C" ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream) {
     return ShareSuccess;
 }
 
+// ---- HIP graphs ----------------------------------------------------------------------------------
+struct hbmpc_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+extern "C" ShareErrorCode hbmpc_graph_begin_capture(hbmpc_ctx* ctx, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!stream) return fail(ctx, InvalidInput, "graph capture needs an explicit stream");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_graph_end_capture(hbmpc_ctx* ctx, void* stream, hbmpc_graph** graph_out) {
+    if (!ctx || !graph_out) return InvalidInput;
+    *graph_out = nullptr;
+    if (!stream) return fail(ctx, InvalidInput, "graph capture needs an explicit stream");
+    hbmpc_graph* g = new hbmpc_graph();
+    hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        g_err = std::string("graph capture failed: ") + hipGetErrorString(e);
+        hbmpc_graph_destroy(g);
+        return HBMPC_NO_DEVICE;
+    }
+    *graph_out = g;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_graph_launch(hbmpc_ctx* ctx, hbmpc_graph* graph, void* stream) {
+    if (!ctx || !graph || !graph->exec) return InvalidInput;
+    HIP_TRY(ctx, hipGraphLaunch(graph->exec, pick(ctx, stream)));
+    return ShareSuccess;
+}
+extern "C" void hbmpc_graph_destroy(hbmpc_graph* graph) {
+    if (!graph) return;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
+}
+
 // ---- a3 / a5: evaluation on the domain ---------------------------------------------------------
 static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, uint32_t* y,
                                 hipStream_t s) {

@@ -258,6 +258,27 @@ class Engine:
         return self._f("dev_fr_op")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), C.c_void_p(a_d),
                                       C.c_void_p(b_d), C.c_size_t(N), C.c_void_p(out_d), C.c_void_p(stream))
 
+    # ---- HIP graphs: capture a sequence of dev_* calls once, replay it per refill of the buffers ----
+    def graph_begin(self, stream):
+        rc = self.L.hbmpc_graph_begin_capture(self.ctx, C.c_void_p(stream))
+        if rc != 0:
+            raise HbmpcError(f"graph_begin_capture -> {rc}: {self.last_error()}")
+
+    def graph_end(self, stream) -> int:
+        g = C.c_void_p()
+        rc = self.L.hbmpc_graph_end_capture(self.ctx, C.c_void_p(stream), C.byref(g))
+        if rc != 0:
+            raise HbmpcError(f"graph_end_capture -> {rc}: {self.last_error()}")
+        return g.value
+
+    def graph_launch(self, graph: int, stream=0):
+        rc = self.L.hbmpc_graph_launch(self.ctx, C.c_void_p(graph), C.c_void_p(stream))
+        if rc != 0:
+            raise HbmpcError(f"graph_launch -> {rc}: {self.last_error()}")
+
+    def graph_destroy(self, graph: int):
+        self.L.hbmpc_graph_destroy(C.c_void_p(graph))
+
     def sync(self, stream=0):
         rc = self.L.hbmpc_stream_sync(self.ctx, C.c_void_p(stream))
         if rc != 0:

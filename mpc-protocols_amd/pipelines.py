@@ -47,7 +47,32 @@ def _summary_ok(eng, smd, what, stream=0):
     return int(s[0])
 
 
-class TripleGen:
+class _Capturable:
+    """run(check=False) only enqueues hbmpc_dev_* calls; after one eager run (tables and scratch then exist) the same
+    sequence can be captured into a HIP graph and replayed, which removes the per-launch overhead that dominates at
+    the small batch sizes the protocols actually use."""
+    graph = None
+
+    def capture(self):
+        assert self.stream, "capture needs an explicit stream"
+        self.run(check=False)
+        self.eng.sync(self.stream)
+        self.eng.graph_begin(self.stream)
+        try:
+            self.run(check=False)
+        finally:
+            self.graph = self.eng.graph_end(self.stream)
+
+    def replay(self):
+        self.eng.graph_launch(self.graph, self.stream)
+
+    def _drop_graph(self):
+        if self.graph:
+            self.eng.graph_destroy(self.graph)
+            self.graph = None
+
+
+class TripleGen(_Capturable):
     """n parties, threshold t, N triples (N a multiple of 2t+1).  Buffers are [party][N] canonical."""
 
     def __init__(self, eng, n, t, N, stream=0):
@@ -104,10 +129,11 @@ class TripleGen:
         return out
 
     def close(self):
+        self._drop_graph()
         self.arena.free()
 
 
-class FpMul:
+class FpMul(_Capturable):
     """Fixed-point multiplication of N element pairs for n parties: Beaver mul (a-x, b-y opened by direct
     robust interpolation, i.e. the RBC path of Multiply::init for < t+1 leftovers that FPMulNode always
     takes) followed by TruncPr with k-bit values and m fractional bits."""
@@ -131,9 +157,13 @@ class FpMul:
     def _open(self, shares, out, what):
         e, n, t, N, s = self.eng, self.n, self.t, self.N, self.stream
         _check(e.dev_batch_recover(list(range(n)), shares, N, n, t, t, out, 0, self.status, self.summ, s, p0=True), e, what)
-        _summary_ok(e, self.summ, what, s)
+        if self.check:
+            _summary_ok(e, self.summ, what, s)
 
-    def run(self):
+    def run(self, check=True):
+        """check=False enqueues only (no copy-back, no sync): the whole pipeline is then capturable into a HIP graph
+        once tables and scratch exist (after one eager run)."""
+        self.check = check
         e, n, N, k, m, s = self.eng, self.n, self.N, self.k, self.m, self.stream
         o = lambda p: p * N * U  # noqa: E731
         for p in range(n):   # multiplication.rs:417-426
@@ -161,4 +191,5 @@ class FpMul:
         return out
 
     def close(self):
+        self._drop_graph()
         self.arena.free()

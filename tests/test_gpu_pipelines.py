@@ -90,3 +90,39 @@ def test_fpmul_pipeline(pkg_eng, n, t, N, k, m):
     for p in range(n):
         rd = O.truncpr_rdash(np.ascontiguousarray(sbits[p]), m)[1]
         assert GU.eq(out[p], O.truncpr_finalize(z[p], rd, c_open, m)[1])
+
+
+def test_fpmul_pipeline_as_hip_graph(pkg_eng):
+    """The whole fpmul call sequence captured once into a HIP graph (hbmpc_graph_*) and replayed on refilled
+    buffers gives exactly what the eager calls give."""
+    pkg, eng = pkg_eng
+    n, t, N, k, m = 7, 2, 300, 16, 4
+    # a real (non-NULL) stream for the capture: created through HIP by torch, passed as a raw handle
+    torch = pytest.importorskip("torch")
+    ts = torch.cuda.Stream(device=torch.device("cuda", 0))
+    fp = pkg.pipelines.FpMul(eng, n, t, N, k, m, stream=ts.cuda_stream)
+    rng = np.random.default_rng(99)
+
+    def fill(seed):
+        half = (k - 2) // 2
+        x = O.ints_to_u256([int(v) for v in rng.integers(0, 1 << half, N)])
+        y = O.ints_to_u256([int(v) for v in rng.integers(0, 1 << half, N)])
+        ta, tb = O.fill_random(seed, N), O.fill_random(seed + 1, N)
+        tc = O.fr_binop("mul", ta, tb)
+        rint = O.ints_to_u256([int(v) for v in rng.integers(0, 1 << 40, N)])
+        bits = rng.integers(0, 2, (m, N))
+        sb = np.stack([share_all(O.ints_to_u256([int(v) for v in bits[j]]), n, t, seed + 10 + j) for j in range(m)], axis=1)
+        fp.upload(share_all(x, n, t, seed + 2), share_all(y, n, t, seed + 3), share_all(ta, n, t, seed + 4),
+                  share_all(tb, n, t, seed + 5), share_all(tc, n, t, seed + 6), np.ascontiguousarray(sb),
+                  share_all(rint, n, t, seed + 7))
+
+    fill(500)
+    fp.capture()                                  # one eager run, then the same calls recorded
+    for seed in (500, 600, 700):
+        fill(seed)
+        fp.run()                                  # eager (checked) on this data
+        want = fp.download("out").copy()
+        eng.h2d(fp.out, np.zeros_like(want), ts.cuda_stream)
+        fp.replay()
+        assert GU.eq(fp.download("out"), want), seed
+    fp.close()
