@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/hbmpc_golden.json from oracle/spec.py (Python big-ints).
+"""Generates tests/golden/hbmpc_golden.json from oracle/spec.py (Python big-ints) and
+tests/golden/hbmpc_golden_gl.json from oracle/spec_gl.py (the same restatement over Goldilocks).
 
 The reference holds no golden vectors for this path and cannot be run here,
 so these vectors come from the independent big-int restatement; inputs reuse the literal inputs
@@ -13,19 +14,24 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import spec as S  # noqa: E402
-
-R = S.R_MOD
-H = lambda v: format(v % R, "064x")  # noqa: E731
-
-
-def hx(x):
-    return [hx(y) for y in x] if isinstance(x, (list, tuple)) else H(x)
+from oracle import spec as SPEC_FR  # noqa: E402
+from oracle.spec_gl import S as SPEC_GL  # noqa: E402
 
 
 def main():
+    build(SPEC_FR, "hbmpc_golden.json", 64, True)
+    build(SPEC_GL, "hbmpc_golden_gl.json", 16, False)   # TruncPr is big-field-only in the reference
+
+
+def build(S, fname, hexdigits, with_truncpr):
+    R = S.R_MOD
+    H = lambda v: format(v % R, "0%dx" % hexdigits)  # noqa: E731
+
+    def hx(x):
+        return [hx(y) for y in x] if isinstance(x, (list, tuple)) else H(x)
+
     rng = S.SplitMix64(0xC0FFEE00)
-    out = {"modulus": format(R, "064x"), "cases": []}
+    out = {"modulus": format(R, "0%dx" % hexdigits), "cases": []}
     add = out["cases"].append
     lit = [S.from_limbs([3, 3, 22, 22]), S.from_limbs([520, 86, 9, 18]), S.from_limbs([16, 33, 44, 81]),
            42, 918520, 0, 1, R - 1]
@@ -168,18 +174,18 @@ def main():
     c, d, e = v(), v(), v()
     add({"op": "beaver_finalize", "c": hx(c), "x": hx(x), "y": hx(y), "d": hx(d), "e": hx(e),
          "z": hx([(c[i] - d[i] * e[i] - d[i] * y[i] - e[i] * x[i]) % R for i in range(N)])})
-    for m in (1, 4, 16, 20):
+    for m in ((1, 4, 16, 20) if with_truncpr else ()):
         bits = [v() for _ in range(m)]
         add({"op": "truncpr_rdash", "m": m, "r_bits": hx(bits),
              "r_dash": hx([sum((1 << j) * bits[j][i] for j in range(m)) % R for i in range(N)])})
-    for k, m in ((16, 4), (32, 16), (1, 0), (250, 255)):
+    for k, m in (((16, 4), (32, 16), (1, 0), (250, 255)) if with_truncpr else ()):
         a, rd, ri, co = v(), v(), v(), v()
         add({"op": "truncpr_open_share", "k": k, "m": m, "a": hx(a), "r_dash": hx(rd), "r_int": hx(ri),
              "open": hx([(a[i] + (1 << (k - 1)) + (1 << m) * ri[i] + rd[i]) % R for i in range(N)])})
         add({"op": "truncpr_finalize", "m": m, "a": hx(a), "r_dash": hx(rd), "c_open": hx(co),
              "d": hx([S.truncpr_finalize(S.Share(a[i], 0, 1), S.Share(rd[i], 0, 1), co[i], m).v for i in range(N)])})
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hbmpc_golden.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), fname)
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print(f"wrote {path}: {len(out['cases'])} cases, {os.path.getsize(path)} bytes")

@@ -10,19 +10,23 @@ import numpy as np
 
 from oracle.cref import ints_to_u256
 
-_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hbmpc_golden.json")
+_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_FILES = {"fr": "hbmpc_golden.json", "goldilocks": "hbmpc_golden_gl.json"}
+_FIELD = "fr"  # the field of the case set being checked (set by run_all)
 
 
-def load():
-    with open(_PATH) as f:
+def load(field="fr"):
+    with open(os.path.join(_DIR, _FILES[field])) as f:
         return json.load(f)["cases"]
 
 
 def U(h):
-    """nested hex lists -> uint64[...,4]"""
+    """nested hex lists -> uint64[...,4] (Fr) or uint64[...] (Goldilocks)"""
     def conv(x):
         return [conv(y) for y in x] if isinstance(x, list) else int(x, 16)
     arr = conv(h)
+    if _FIELD == "goldilocks":
+        return np.array(arr, dtype=np.uint64)
     if isinstance(arr, list) and len(arr) == 0:
         return np.zeros((0, 4), dtype=np.uint64)
     return ints_to_u256(arr)
@@ -94,8 +98,13 @@ def check_case(E, c):
         raise AssertionError("unknown op " + op)
 
 
-def run_all(E):
-    cases = load()
-    for c in cases:
-        check_case(E, c)
+def run_all(E, field="fr"):
+    global _FIELD
+    _FIELD = field
+    try:
+        cases = load(field)
+        for c in cases:
+            check_case(E, c)
+    finally:
+        _FIELD = "fr"
     return len(cases)

@@ -289,3 +289,8 @@ def test_full_size_roundtrip_and_linearity(eng):
     assert bool((sec == x[:, 0]).all()) and summ.tolist()[:2] == [G // 64, 0]
     assert int(st[::64].min()) == 1 and int(st[1::64].max()) == 0
     torch.cuda.set_stream(torch.cuda.default_stream(dev))
+
+
+def test_golden_vectors(eng):
+    from tests import golden_util as GU
+    assert GU.run_all(eng, field="goldilocks") > 90

@@ -52,3 +52,79 @@ def test_batch_recover_matches_per_chunk():                             # robust
         ev[b] = (ev[b][0], [(v + 7 * (c + 1) + b) % P for c, v in enumerate(ev[b][1])])
     out = S.batch_recover_secret(ev, n, d, t)
     assert [o[0] for o in out] == [p[0] for p in polys]
+
+
+class SpecEngine:
+    """oracle/spec_gl.py behind the engine interface tests/golden_util.py drives (numpy uint64 in, (rc, ...) out)"""
+
+    def __init__(self, S):
+        self.S = S
+
+    @staticmethod
+    def _a(x):
+        import numpy as np
+        return np.array(x, dtype=np.uint64)
+
+    def _try(self, fn):
+        try:
+            return (0,) + tuple(fn())
+        except self.S.ShareErr as e:
+            return (e.code,) + (None,) * 4
+
+    def make_vandermonde(self, n, d):
+        return 0, self._a(self.S.make_vandermonde(n, d))
+
+    def compute_shares(self, coeffs, n, d):
+        cols = [[s.v for s in self.S.compute_shares([int(c) for c in row], n, d)] for row in coeffs]
+        return 0, self._a(cols).T.copy() if len(cols) else self._a([[]] * n)
+
+    def vandermonde_apply(self, x, n, d):
+        return self.compute_shares(x, n, d)
+
+    def batch_recover(self, ids, ev, n, d, t):
+        import numpy as np
+        evs = [(i, [int(v) for v in ev[k]]) for k, i in enumerate(ids)]
+        try:
+            res = self.S.batch_recover_secret(evs, n, d, t)
+        except self.S.ShareErr as e:
+            return e.code, None, None, None
+        return 0, self._a([r + [0] * (d + 1 - len(r)) for r in res]), [len(r) for r in res], np.zeros(len(res))
+
+    def batch_recover_p0(self, ids, ev, n, d, t):
+        rc, co, nco, st = self.batch_recover(ids, ev, n, d, t)
+        return rc, (co[:, 0] if rc == 0 else None), st
+
+    def recover_secret(self, ids, degrees, vals, n, t):
+        sh = [self.S.Share(int(v), i, dg) for v, i, dg in zip(vals, ids, degrees)]
+        r = self._try(lambda: self.S.recover_secret(sh, n, t))
+        return (r[0], self._a(r[1]), self._a(r[2])) if r[0] == 0 else (r[0], None, None)
+
+    def gao_rs_decode(self, received, k, n, erasures):
+        r = self._try(lambda: (self.S.gao_rs_decode([int(v) for v in received], k, n, erasures),))
+        return (0, self._a(r[1])) if r[0] == 0 else (r[0], None)
+
+    def nonrobust_recover_secret(self, ids, degrees, vals, n):
+        sh = [self.S.Share(int(v), i, dg) for v, i, dg in zip(vals, ids, degrees)]
+        r = self._try(lambda: self.S.nonrobust_recover_secret(sh, n))
+        return (r[0], self._a(r[1]), self._a(r[2])) if r[0] == 0 else (r[0], None, None)
+
+    def triple_local(self, a, b, r2t):
+        return 0, self._a([(int(x) * int(y) - int(z)) % P for x, y, z in zip(a, b, r2t)])
+
+    def triple_finalize(self, rt, opened):
+        return 0, self._a([(int(x) + int(y)) % P for x, y in zip(rt, opened)])
+
+    def beaver_open_shares(self, a, b, x, y):
+        return (0, self._a([(int(p) - int(q)) % P for p, q in zip(a, x)]),
+                self._a([(int(p) - int(q)) % P for p, q in zip(b, y)]))
+
+    def beaver_finalize(self, c, x, y, d, e):
+        return 0, self._a([(int(c[i]) - int(d[i]) * int(e[i]) - int(d[i]) * int(y[i]) - int(e[i]) * int(x[i])) % P
+                           for i in range(len(c))])
+
+
+def test_goldilocks_golden_vectors_match_the_oracle():
+    """tests/golden/hbmpc_golden_gl.json (generated by tests/golden/make_golden.py) is what oracle/spec_gl.py
+    computes today: guards the committed fixtures against drift of the restatement."""
+    from tests import golden_util as GU
+    assert GU.run_all(SpecEngine(S), field="goldilocks") > 90
