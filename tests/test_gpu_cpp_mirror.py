@@ -8,12 +8,26 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "test_reference_units")
+CBIN = os.path.join(ROOT, "tests", "cpp", "test_c_abi")
 
 
 def test_cpp_mirror_builds():
     # host-only g++ compile + link against the in-tree library (no GPU needed)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
-    assert os.path.exists(BIN)
+    assert os.path.exists(BIN) and os.path.exists(CBIN)
+
+
+def test_header_is_plain_c99():
+    subprocess.check_call(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                           os.path.join(ROOT, "include", "hbmpc_hip.h")])
+
+
+@pytest.mark.gpu
+def test_c99_caller_round_trips():
+    if not os.path.exists(CBIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    p = subprocess.run([CBIN], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "C ABI round trips passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 @pytest.mark.gpu
