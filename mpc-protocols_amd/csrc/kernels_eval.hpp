@@ -13,7 +13,9 @@
 // n=31,d=10 costs 44 per chunk (direct: 341).
 // Layout: input chunk-major x[G][d+1] is staged through LDS with coalesced 16-byte loads (one
 // wave-tile = 64 chunks, rows padded by 16 B so the per-lane ds_read_b128 is bank-conflict free);
-// output party-major y[n][G]: a wave stores 2 KiB contiguous per party.
+// output party-major y[n][G]: a wave stores 2 KiB contiguous per party, each output canonicalised and
+// stored as soon as the last stage produces it.  The same templates are instantiated for the
+// Goldilocks field (fr_gold.hpp, 8-byte elements: F::EW = 2).
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -232,17 +234,6 @@ HB_DEV void load_twisted(typename F::E (&X)[16], const uint32_t* __restrict__ ro
                          int dp1, bool fold, std::integer_sequence<int, P...>) {
     (load_twisted_one<F, CNT, P>(X, row, tr, dp1, fold), ...);
 }
-template <class F, int S, int I>
-HB_DEV void store_one(const typename F::E (&X)[S], uint32_t* __restrict__ y, size_t G, size_t g, int r, int P, int n) {
-    const int j = r + P * I;
-    if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, X[I]);
-}
-template <class F, int S, int... I>
-HB_DEV void store_all(const typename F::E (&X)[S], uint32_t* __restrict__ y, size_t G, size_t g, int r, int P, int n,
-                      std::integer_sequence<int, I...>) {
-    (store_one<F, S, I>(X, y, G, g, r, P, n), ...);
-}
-
 // ---------------------------------------------------------------------------------------------
 // single-pass kernel: size = 2^LOG <= 16, DP1 = CNT coefficients
 // ---------------------------------------------------------------------------------------------
