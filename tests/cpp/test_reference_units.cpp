@@ -287,6 +287,109 @@ static void c_abi_secret_share_roundtrip() {
     CHECK(RobustShare::compute_shares(secret, 2, 2, nullptr, rng).unwrap_err() == InvalidInput);  // n <= degree
 }
 
+
+// ---- the same properties over the generic Scheme<FieldTraits>, instantiated for BOTH fields ----------------
+// (the reference's functions are generic over F; its small-field nodes run them over GoldilocksField)
+template <class S>
+static typename S::Rng field_rng(uint64_t seed);
+template <>
+FrScheme::Rng field_rng<FrScheme>(uint64_t seed) { return test_rng(seed); }
+template <>
+GlScheme::Rng field_rng<GlScheme>(uint64_t seed) {
+    auto state = std::make_shared<uint64_t>(seed);
+    return [state]() {
+        for (;;) {  // rejection sampling below p = 2^64 - 2^32 + 1
+            uint64_t z = (*state += 0x9E3779B97F4A7C15ULL);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            z ^= z >> 31;
+            if (z < 0xFFFFFFFF00000001ULL) return GlScheme::F(z);
+        }
+    };
+}
+template <class S>
+static void generic_share_recover_and_operators() {
+    using F = typename S::F;
+    using RSh = typename S::template ShamirShare<Robust>;
+    auto rng = field_rng<S>(7);
+    const size_t n = 10, t = 3;
+    const F secret = F::from(918520);
+    auto shares = S::RobustShare::compute_shares(secret, n, t, nullptr, rng).unwrap();
+    CHECK(shares.size() == n && shares[4].id == 4 && shares[4].degree == t);
+    auto rec = S::RobustShare::recover_secret(shares, n, t).unwrap();
+    CHECK(rec.second == secret && rec.first.size() == t + 1);
+    // up to t lies are corrected, t + 1 are not (n = 3t + 1)
+    auto bad = shares;
+    for (size_t i = 0; i < t; ++i) bad[2 * i].share += F::from(5 + i);
+    CHECK(S::RobustShare::recover_secret(bad, n, t).unwrap().second == secret);
+    bad[9].share += F::one();
+    CHECK(S::RobustShare::recover_secret(bad, n, t).is_err());
+    // share algebra: (a + b) and (a * c) open to the sums / products; mismatches report degree before id
+    auto sh2 = S::RobustShare::compute_shares(F::from(42), n, t, nullptr, rng).unwrap();
+    std::vector<RSh> sum, scaled;
+    for (size_t i = 0; i < n; ++i) {
+        sum.push_back((shares[i] + sh2[i]).unwrap());
+        scaled.push_back((shares[i] * F::from(3)).unwrap());
+    }
+    CHECK(S::RobustShare::recover_secret(sum, n, t).unwrap().second == F::from(918520 + 42));
+    CHECK(S::RobustShare::recover_secret(scaled, n, t).unwrap().second == F::from(3 * 918520));
+    CHECK((shares[0] + sh2[1]).unwrap_err() == IdMismatch);
+    CHECK((shares[0] + RSh(F::one(), 1, t + 1)).unwrap_err() == DegreeMismatch);
+    CHECK(shares[0].share_mul(sh2[0]).unwrap().degree == 2 * t);
+    CHECK(S::RobustShare::compute_shares(secret, 3, 3, nullptr, rng).unwrap_err() == InvalidInput);
+    // non-robust: plain interpolation through all shares, degree check
+    auto ns = S::NonRobustShare::compute_shares(secret, 6, 5, nullptr, rng).unwrap();
+    CHECK(S::NonRobustShare::recover_secret(ns, 6, 0).unwrap().second == secret);
+    ns.pop_back();
+    CHECK(S::NonRobustShare::recover_secret(ns, 6, 0).unwrap_err() == InsufficientShares);
+}
+template <class S>
+static void generic_vandermonde_and_batch_recover() {
+    using F = typename S::F;
+    using RSh = typename S::template ShamirShare<Robust>;
+    auto rng = field_rng<S>(11);
+    const size_t n = 7, t = 2, d = 2, G = 5;
+    auto vdm = S::make_vandermonde(n, d).unwrap();
+    for (size_t j = 0; j < n; ++j) {
+        CHECK(vdm[j][0] == F::one() && vdm[j][1] == S::domain_element(n, j) && vdm[j][2] == vdm[j][1] * vdm[j][1]);
+        CHECK(!vdm[j][1].is_zero());
+    }
+    // BatchRecon's encode: chunks of d + 1 shares of one party -> one evaluation per recipient
+    std::vector<std::vector<F>> polys(G, std::vector<F>(d + 1));
+    std::vector<std::pair<size_t, std::vector<F>>> by_sender(n);
+    for (size_t j = 0; j < n; ++j) by_sender[j].first = n - 1 - j;  // arrival order reversed
+    for (size_t c = 0; c < G; ++c) {
+        std::vector<RSh> chunk;
+        for (size_t k = 0; k <= d; ++k) {
+            polys[c][k] = rng();
+            chunk.emplace_back(polys[c][k], 3, t);
+        }
+        auto y = S::template apply_vandermonde<Robust>(vdm, chunk).unwrap();
+        CHECK(y.size() == n && y[0].id == 3 && y[0].degree == t);
+        for (size_t j = 0; j < n; ++j) by_sender[n - 1 - j].second.push_back(y[j].share);
+    }
+    auto out = S::batch_recover_secret(by_sender, n, d, t).unwrap();
+    for (size_t c = 0; c < G; ++c) CHECK(out[c] == polys[c]);
+    // t corrupted senders: every chunk takes the OEC/Gao path and still opens to the same polynomials
+    for (size_t b = 0; b < t; ++b)
+        for (size_t c = 0; c < G; ++c) by_sender[b].second[c] += F::from(7 * (c + 1) + b);
+    out = S::batch_recover_secret(by_sender, n, d, t).unwrap();
+    for (size_t c = 0; c < G; ++c) CHECK(out[c][0] == polys[c][0]);
+    by_sender.resize(d + t);  // not enough evaluations
+    CHECK(S::batch_recover_secret(by_sender, n, d, t).unwrap_err() == InvalidInput);
+    // Reed-Solomon with erasures and errors on its own
+    std::vector<F> msg = {F::from(3), F::from(1), F::from(4)}, cw;
+    for (size_t i = 0; i < 10; ++i) {
+        F acc = F::zero();
+        const F x = S::domain_element(10, i);
+        for (size_t k = msg.size(); k-- > 0;) acc = acc * x + msg[k];
+        cw.push_back(acc);
+    }
+    cw[1] += F::one();
+    cw[8] += F::from(99);
+    CHECK(S::gao_rs_decode(cw, 3, 10, {4, 6}).unwrap() == msg);
+}
+
 int main() {
     RUN(test_make_vandermonde_basic);
     RUN(test_apply_vandermonde_basic);
@@ -307,6 +410,10 @@ int main() {
     RUN(test_batch_recover_secret_matches_per_chunk);
     RUN(test_batch_recover_secret_with_corruption);
     RUN(c_abi_secret_share_roundtrip);
+    RUN(generic_share_recover_and_operators<FrScheme>);
+    RUN(generic_share_recover_and_operators<GlScheme>);
+    RUN(generic_vandermonde_and_batch_recover<FrScheme>);
+    RUN(generic_vandermonde_and_batch_recover<GlScheme>);
     std::printf(g_failed ? "%d CHECKS FAILED\n" : "all reference unit tests passed (%d failures)\n", g_failed);
     return g_failed ? 1 : 0;
 }
