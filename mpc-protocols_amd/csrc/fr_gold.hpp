@@ -20,7 +20,11 @@ struct Gold {
     static constexpr int NL = 2;  // words per constant
     static constexpr int EW = 2;  // words per stored element
     template <int LOG, int CNT>
-    static constexpr int eval_waves() { return 8; }  // memory-bound: as many waves as fit
+    static constexpr int eval_waves() { return 8; }  // memory-bound: as many waves as fit ...
+    template <int LOG, int CNT>
+    static constexpr int eval_waves_min() { return 1; }  // ... but never at the price of spills
+    template <int LOG, int CNT>
+    static constexpr bool eval_interleave() { return false; }
     static constexpr int MAX_DOT_TERMS = 1 << 30;
     static constexpr uint64_t P = 0xFFFFFFFF00000001ull;
     static constexpr uint64_t EPS = 0xFFFFFFFFull;
@@ -28,8 +32,12 @@ struct Gold {
     struct E {
         uint32_t l[2];
     };
+    // Lazy dot products (the role U29's column accumulators play): a term is NOT reduced.  With a = a1 2^32 + a0 the
+    // two partial products a0*c and a1*c are < 2^96 each and are summed in two 128-bit accumulators -- plain
+    // add-with-carry chains, 2^32 terms of headroom -- and one reduction per dot product folds them:
+    // sum = lo + 2^32 hi (mod p).  (A reduced multiply-add per term costs ~45 instructions here, this ~14.)
     struct Acc {
-        E s;
+        unsigned __int128 lo, hi;
     };
     static HB_DEV uint64_t u(const E& a) { return ((uint64_t)a.l[1] << 32) | a.l[0]; }
     static HB_DEV E e(uint64_t v) {
@@ -75,14 +83,29 @@ struct Gold {
     static HB_DEV E mulc_u(const E& a, const uint32_t* __restrict__ c) { return mont(a, c); }
     static HB_DEV E mont(const E& a, const E& b) { return e(mulm(u(a), u(b))); }
 
-    static HB_DEV void acc_zero(Acc& A) { A.s = zero(); }
-    static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) { A.s = add(A.s, mont(a, c)); }
-    static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[2]) { A.s = add(A.s, mont(a, c)); }
-    static HB_DEV void acc_add_hi(Acc& A, const E& x) { A.s = add(A.s, x); }
+    static HB_DEV void acc_zero(Acc& A) { A.lo = 0, A.hi = 0; }
+    static HB_DEV void acc_mac_u64(Acc& A, uint64_t a, uint64_t c) {
+        A.lo += (unsigned __int128)(uint32_t)a * c;
+        A.hi += (unsigned __int128)(uint32_t)(a >> 32) * c;
+    }
+    static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) { acc_mac_u64(A, u(a), ((uint64_t)c[1] << 32) | c[0]); }
+    static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[2]) { acc_mac_u64(A, u(a), ((uint64_t)c[1] << 32) | c[0]); }
+    static HB_DEV void acc_add_hi(Acc& A, const E& x) { A.lo += u(x); }
     static HB_DEV void acc_fold(Acc&) {}
     template <int M_TOTAL>
     static HB_DEV void acc_fold_needed(Acc&) {}
-    static HB_DEV E acc_reduce(Acc& A) { return A.s; }
+    // x < 2^128 -> canonical residue: x = lo + 2^64 (hl + 2^32 hh) = lo - hh + hl * EPS (mod p)
+    static HB_DEV uint64_t reduce128(unsigned __int128 x) {
+        const uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+        const uint64_t hh = hi >> 32, hl = hi & EPS;
+        uint64_t t0 = lo - hh;
+        if (lo < hh) t0 -= EPS;
+        const uint64_t t1 = hl * EPS;
+        uint64_t r = t0 + t1;
+        if (r < t0) r += EPS;
+        return r >= P ? r - P : r;
+    }
+    static HB_DEV E acc_reduce(Acc& A) { return e(addm(reduce128(A.lo), mulm(reduce128(A.hi), 1ull << 32))); }
 
     static HB_DEV E cond_sub_r(const E& x) { return x; }
     static HB_DEV E canon_loose(const E& x) { return x; }

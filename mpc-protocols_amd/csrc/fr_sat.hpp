@@ -19,6 +19,10 @@ struct Sat32 {
     static constexpr int EW = 8;  // u32 words per stored element
     template <int LOG, int CNT>
     static constexpr int eval_waves() { return 2; }
+    template <int LOG, int CNT>
+    static constexpr int eval_waves_min() { return 1; }
+    template <int LOG, int CNT>
+    static constexpr bool eval_interleave() { return false; }
     static constexpr int MAX_DOT_TERMS = 1 << 30;
 
     struct E {

@@ -42,6 +42,10 @@ struct U29 {
     // fit 168 VGPRs; with more inputs all 16 values are live and the kernel stays at 2 waves.
     template <int LOG, int CNT>
     static constexpr int eval_waves() { return (LOG < 4 || CNT <= 6) ? 3 : 2; }
+    template <int LOG, int CNT>
+    static constexpr int eval_waves_min() { return eval_waves<LOG, CNT>(); }  // forced: the register budget is the point
+    template <int LOG, int CNT>
+    static constexpr bool eval_interleave() { return eval_waves<LOG, CNT>() == 3; }
     static constexpr int MAX_DOT_TERMS = 6;
 
     struct E {

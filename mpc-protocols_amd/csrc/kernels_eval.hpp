@@ -140,6 +140,14 @@ HB_DEV void fft_last_two_sink(typename F::E (&X)[1 << LOG], const uint32_t* __re
                               std::integer_sequence<int, K...>) {
     (fft_last_two_quarter<F, LOG, CNT, LBU0, VB0, K>(X, tw, sink), ...);
 }
+// plain order: all of stage LOG-2, then the last stage with the sink after each butterfly
+template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink, int... IDX>
+HB_DEV void fft_last_stage_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink,
+                                std::integer_sequence<int, IDX...>) {
+    ((fft_bfly<F, LOG, CNT, LBU0, VB0, LOG - 1, IDX>(X, tw), sink(std::integral_constant<int, IDX>{}, X[IDX]),
+      sink(std::integral_constant<int, IDX + (1 << (LOG - 1))>{}, X[IDX + (1 << (LOG - 1))])),
+     ...);
+}
 template <class F, int LOG, int CNT, int LBU0, int VB0, class Sink>
 HB_DEV void fft_pruned_sink(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ tw, Sink&& sink) {
     if constexpr (LOG == 0) {
@@ -148,9 +156,12 @@ HB_DEV void fft_pruned_sink(typename F::E (&X)[1 << LOG], const uint32_t* __rest
         fft_bfly<F, 1, CNT, LBU0, VB0, 0, 0>(X, tw);
         sink(std::integral_constant<int, 0>{}, X[0]);
         sink(std::integral_constant<int, 1>{}, X[1]);
-    } else {
+    } else if constexpr (F::template eval_interleave<LOG, CNT>()) {
         if constexpr (LOG > 2) fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG - 2>{});
         fft_last_two_sink<F, LOG, CNT, LBU0, VB0>(X, tw, sink, std::make_integer_sequence<int, (1 << LOG) / 4>{});
+    } else {  // all 16 values are live anyway (more than 6 non-zero inputs): the plain order schedules better
+        fft_stages<F, LOG, CNT, LBU0, VB0>(X, tw, std::make_integer_sequence<int, LOG - 1>{});
+        fft_last_stage_sink<F, LOG, CNT, LBU0, VB0>(X, tw, sink, std::make_integer_sequence<int, (1 << LOG) / 2>{});
     }
 }
 template <int LOG, int CNT, int LBU0, int VB0>
@@ -238,7 +249,7 @@ HB_DEV void load_twisted(typename F::E (&X)[16], const uint32_t* __restrict__ ro
 // single-pass kernel: size = 2^LOG <= 16, DP1 = CNT coefficients
 // ---------------------------------------------------------------------------------------------
 template <class F, int LOG, int CNT>
-__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves<LOG, CNT>(), F::template eval_waves<LOG, CNT>()))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves_min<LOG, CNT>(), F::template eval_waves<LOG, CNT>()))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
                                                          const uint32_t* __restrict__ tw, uint32_t* __restrict__ y) {
     using E = typename F::E;
     constexpr int S = 1 << LOG;
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
 // CNT16 = min(dp1, 16).  FOLD = dp1 > 16.
 // ---------------------------------------------------------------------------------------------
 template <class F, int CNT16, bool FOLD>
-__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves<4, CNT16 + (FOLD ? 16 : 0)>(), F::template eval_waves<4, CNT16 + (FOLD ? 16 : 0)>()))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves_min<4, CNT16 + (FOLD ? 16 : 0)>(), F::template eval_waves<4, CNT16 + (FOLD ? 16 : 0)>()))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
                                                          int P, const uint32_t* __restrict__ tw16,
                                                          const uint32_t* __restrict__ twist,
                                                          uint32_t* __restrict__ y) {
