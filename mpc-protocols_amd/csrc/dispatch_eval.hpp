@@ -9,7 +9,7 @@ namespace hbmpc {
 template <class F, int LOG, int CNT>
 inline void launch_fft1_one(const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s) {
     const unsigned grid = (unsigned)((G + EVAL_TILE - 1) / EVAL_TILE);
-    const size_t lds = (size_t)EVAL_TILE * (CNT * F::EW + (F::EW >= 4 ? 4 : 2)) * 4;
+    const size_t lds = (size_t)EVAL_TILE * (CNT * F::EW + TILE_PAD<F::EW>) * 4;
     hipLaunchKernelGGL((k_eval_fft1<F, LOG, CNT>), dim3(grid), dim3(EVAL_TILE), lds, s, x, G, n, tw, y);
 }
 // cnt in [LO, LO + sizeof...(I))
@@ -24,7 +24,7 @@ template <class F, int CNT16, bool FOLD>
 inline void launch_fftP_one(const uint32_t* x, size_t G, int n, int dp1, int P, const uint32_t* tw16,
                             const uint32_t* twist, uint32_t* y, hipStream_t s) {
     const unsigned grid = (unsigned)((G + EVAL_TILE - 1) / EVAL_TILE);
-    const size_t lds = (size_t)EVAL_TILE * (dp1 * F::EW + (F::EW >= 4 ? 4 : 2)) * 4;
+    const size_t lds = (size_t)EVAL_TILE * (dp1 * F::EW + TILE_PAD<F::EW>) * 4;
     hipLaunchKernelGGL((k_eval_fftP<F, CNT16, FOLD>), dim3(grid), dim3(EVAL_TILE), lds, s, x, G, n, dp1, P, tw16, twist,
                        y);
 }

@@ -12,7 +12,7 @@
 // would multiply two non-trivial values: n=16,d=5 costs 15 modmuls per secret (direct: 80),
 // n=31,d=10 costs 44 per chunk (direct: 341).
 // Layout: input chunk-major x[G][d+1] is staged through LDS with coalesced 16-byte loads (one
-// wave-tile = 64 chunks, rows padded by 16 B so the per-lane ds_read_b128 is bank-conflict free);
+// wave-tile = 64 chunks, rows unpadded: LDS capacity, not LDS bank conflicts, is what matters here);
 // output party-major y[n][G]: a wave stores 2 KiB contiguous per party, each output canonicalised and
 // stored as soon as the last stage produces it.  The same templates are instantiated for the
 // Goldilocks field (fr_gold.hpp, 8-byte elements: F::EW = 2).
@@ -176,13 +176,19 @@ constexpr int fft_max_vb() {
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS tile: 64 chunks x DP1 elements, row pitch DP1*32 + 16 bytes
+// LDS tile: 64 chunks x DP1 elements, row pitch DP1 * element bytes (+ TILE_PAD words)
 // ---------------------------------------------------------------------------------------------
 constexpr int EVAL_TILE = 64;  // chunks per wave-tile (= one wavefront)
 
 // EW = u32 words per element (8: Fr, 2: Goldilocks); a piece is 16 bytes (Fr) or one 8-byte element
+// Row padding of the tile in u32 words.  32-byte elements: none -- a padded row would make the per-lane
+// ds_read_b128 bank-conflict free, but the ~300 LDS reads of a tile are nothing next to its ~14 k VALU
+// instructions, while 16 bytes per row cost a whole wave of occupancy (dp1 = 11: 22.5 KB per wave fits 7 waves per
+// CU, 23.5 KB only 6): measured -4 % on the config-3 encode, -1 % on config 2.
 template <int EW>
-HB_DEV int tile_pitch_words(int dp1) { return dp1 * EW + (EW >= 4 ? 4 : 2); }
+constexpr int TILE_PAD = EW >= 4 ? 0 : 2;
+template <int EW>
+HB_DEV int tile_pitch_words(int dp1) { return dp1 * EW + TILE_PAD<EW>; }
 
 // stage rows [g0, g0+64) of x[G][dp1] into LDS: coalesced 16-byte pieces, wave-uniform bounds.
 // All of a lane's loads (NP = ceil(2*dp1) pieces, compile-time) are issued back-to-back BEFORE the first
