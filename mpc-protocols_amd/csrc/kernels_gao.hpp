@@ -108,23 +108,54 @@ __device__ __noinline__ typename F::E fr_inverse_mont(typename F::E a, const uin
     return acc;
 }
 
-// One block decodes chunks from the flagged list (block-stride loop).
-template <class F, int BLOCK>
+// A GROUP of SUB lanes decodes one chunk (lane = coefficient index, so SUB > n); a workgroup holds BLOCK / SUB
+// groups.  For n < 32 a 64-lane wave would otherwise run a quarter or half empty, so it carries 4 or 2
+// independent chunks: the groups of a wave diverge freely (their EEA / division trip counts differ), every
+// exchange is inside a group, and group synchronisation inside one wave is a fence -- LDS operations of a wave
+// execute in order.  With SUB == BLOCK (n >= 32) a group is the whole workgroup and the barriers are real.
+constexpr size_t gao_group_words(int sub, int nl) { return (size_t)(4 * sub + 4) * nl + 16; }
+template <int BLOCK, int SUB>
+HB_DEV void group_sync() {
+    if constexpr (SUB == BLOCK) {
+        __syncthreads();
+    } else {
+        static_assert(BLOCK == 64, "several groups only within one wave");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+template <int BLOCK, int SUB>
+HB_DEV int group_max(int v, int* scratch) {
+    if constexpr (SUB == BLOCK) {
+        return block_max<BLOCK>(v, scratch);
+    } else {
+        (void)scratch;
+#pragma unroll
+        for (int o = SUB / 2; o > 0; o >>= 1) {
+            const int w = __shfl_xor(v, o);
+            v = w > v ? w : v;
+        }
+        return v;
+    }
+}
+// Groups stride over the flagged list.
+template <class F, int BLOCK, int SUB>
 __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
     using E = typename F::E;
-    constexpr int NL = F::NL;
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    // polynomials: BLOCK coefficients each
+    constexpr int NL = F::NL, NSUB = BLOCK / SUB;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];
+    const int tid = threadIdx.x % SUB, sub = threadIdx.x / SUB;
+    uint32_t* lds = lds_all + (size_t)sub * gao_group_words(SUB, NL);
+    // polynomials: SUB coefficients each
     uint32_t* R0 = lds;
-    uint32_t* R1 = R0 + BLOCK * NL;
-    uint32_t* T0 = R1 + BLOCK * NL;
-    uint32_t* T1 = T0 + BLOCK * NL;
-    uint32_t* BC = T1 + BLOCK * NL;           // broadcast slots: 4 elements
+    uint32_t* R1 = R0 + SUB * NL;
+    uint32_t* T0 = R1 + SUB * NL;
+    uint32_t* T1 = T0 + SUB * NL;
+    uint32_t* BC = T1 + SUB * NL;             // broadcast slots: 4 elements
     int* iscr = reinterpret_cast<int*>(BC + 4 * NL);  // small int scratch (16 ints)
-    const int tid = threadIdx.x;
     const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
 
-    for (size_t fi = blockIdx.x; fi < count; fi += gridDim.x) {
+    for (size_t fi = (size_t)blockIdx.x * NSUB + sub; fi < count; fi += (size_t)gridDim.x * NSUB) {
         const size_t g = a.flagged ? (size_t)a.flagged[fi] : fi;
         int result = DecodingError;  // oec_decode's error when no round succeeds (:625)
         int out_len = 0;
@@ -132,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
         for (int rd = 0; rd < a.n_rounds && !done; ++rd) {
             const GaoRound R = a.rounds[rd];
             const int req = R.required;
-            __syncthreads();
+            group_sync<BLOCK, SUB>();
             // ---- r0 = g0, r1 = g1 = sum_j y_j LB[.][j], t0 = 0, t1 = 1 (Montgomery forms) --------
             {
                 E v0 = F::zero(), v1 = F::zero();
@@ -160,10 +191,10 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 if (tid == 0) one = F::cond_sub_r(F::mulc(F::load_const(a.one_plain), a.r2));
                 lds_put<F>(T1 + tid * NL, one);
             }
-            __syncthreads();
+            group_sync<BLOCK, SUB>();
             uint32_t *r0 = R0, *r1 = R1, *t0 = T0, *t1 = T1;
             int d0 = req;  // deg g0
-            int d1 = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
+            int d1 = group_max<BLOCK, SUB>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
             // ---- EEA: while r1.degree() >= threshold (degree of the zero polynomial is 0) ---------
             while ((d1 < 0 ? 0 : d1) >= R.threshold) {
                 // r0 <- r0 mod r1 (fraction-free), t0 <- t0 - q t1 (same combination); then swap
@@ -179,11 +210,11 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                     }
                     nr = F::canon_loose(nr);
                     nt = F::canon_loose(nt);
-                    __syncthreads();
+                    group_sync<BLOCK, SUB>();
                     lds_put<F>(r0 + tid * NL, nr);
                     lds_put<F>(t0 + tid * NL, nt);
-                    __syncthreads();
-                    d0 = block_max<BLOCK>(F::is_zero_canon(nr) ? -1 : tid, iscr);
+                    group_sync<BLOCK, SUB>();
+                    d0 = group_max<BLOCK, SUB>(F::is_zero_canon(nr) ? -1 : tid, iscr);
                 }
                 uint32_t* tmp = r0;
                 r0 = r1;
@@ -197,16 +228,16 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             }
             // ---- f = g / v with g = r1, v = t1 (:524-537) ------------------------------------------
             const int dg = d1;
-            const int dv = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(t1 + tid * NL)) ? -1 : tid, iscr);
+            const int dv = group_max<BLOCK, SUB>(F::is_zero_canon(lds_get<F>(t1 + tid * NL)) ? -1 : tid, iscr);
             bool ok = true;
             bool scaled = false;  // fq holds l^N * quotient, BC[1] = l^N (Montgomery form)
             int df = -1;  // degree of the quotient (-1: zero polynomial)
             uint32_t* fq = t0;  // quotient coefficients are written over t0 (no longer needed)
             if (dg < 0) {
                 // g == 0: quotient and remainder are zero -> the zero polynomial (degree() = 0 < k)
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
                 lds_put<F>(fq + tid * NL, F::zero());
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
             } else if (dg < dv) {
                 ok = false;  // quotient 0, remainder g != 0
             } else {
@@ -217,9 +248,9 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 // inversion; only an accepted division pays for one (a single-lane Fermat chain, ~100k
                 // instructions -- it used to dominate the fallback when several rounds were needed).
                 const E l = lds_get<F>(t1 + dv * NL);
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
                 lds_put<F>(fq + tid * NL, F::zero());
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
                 for (int top = dg; top >= dv; --top) {
                     const E lead = lds_get<F>(r1 + top * NL);
                     const int sh = top - dv;
@@ -229,14 +260,14 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                     E nq = F::mont(lds_get<F>(fq + tid * NL), l);
                     if (tid == sh) nq = F::add(nq, lead);
                     nq = F::canon_loose(nq);
-                    __syncthreads();
+                    group_sync<BLOCK, SUB>();
                     lds_put<F>(r1 + tid * NL, nr);
                     lds_put<F>(fq + tid * NL, nq);
-                    __syncthreads();
+                    group_sync<BLOCK, SUB>();
                 }
-                const int drem = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
+                const int drem = group_max<BLOCK, SUB>(F::is_zero_canon(lds_get<F>(r1 + tid * NL)) ? -1 : tid, iscr);
                 if (drem >= 0) ok = false;  // remainder must be zero
-                df = block_max<BLOCK>(F::is_zero_canon(lds_get<F>(fq + tid * NL)) ? -1 : tid, iscr);
+                df = group_max<BLOCK, SUB>(F::is_zero_canon(lds_get<F>(fq + tid * NL)) ? -1 : tid, iscr);
                 if ((df < 0 ? 0 : df) >= a.k) ok = false;  // quotient.degree() < k
                 if (ok) {  // l^N, needed by the acceptance count and by the final un-scaling
                     if (tid == 0) {
@@ -245,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                         lds_put<F>(BC + NL, sc);
                     }
                     scaled = true;
-                    __syncthreads();
+                    group_sync<BLOCK, SUB>();
                 }
             }
             if (ok && a.accept_min > 0) {
@@ -265,13 +296,13 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                     hit = F::eq_canon(val, ys) ? 1 : 0;
                 }
                 // block-wide sum via max of prefix counts is overkill: use LDS atomics
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
                 if (tid == 0) iscr[8] = 0;
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
                 if (hit) atomicAdd(&iscr[8], 1);
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
                 if (iscr[8] < a.accept_min) ok = false;
-                __syncthreads();
+                group_sync<BLOCK, SUB>();
             }
             if (ok) {
                 // Write the coefficients, zero padded to out_width.  An accepted division leaves Q' = l^N Q: the
@@ -312,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 }
             }
         }
-        __syncthreads();
+        group_sync<BLOCK, SUB>();
     }
 }
 
