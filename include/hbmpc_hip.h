@@ -103,6 +103,8 @@ ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_h
 ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 ShareErrorCode hbmpc_memcpy_d2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream); /* stream == NULL: the ctx's own stream */
+ShareErrorCode hbmpc_stream_create(hbmpc_ctx* ctx, void** stream_out); /* a non-blocking hipStream_t on the ctx's device */
+ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream);
 
 /* ---- HIP graphs (for hosts without their own HIP binding) ----------------------------------------
  * The reference's regime is many small protocol steps (a few hundred elements per message); a device-resident

@@ -222,6 +222,29 @@ extern "C" ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream) {
     return ShareSuccess;
 }
 
+extern "C" ShareErrorCode hbmpc_stream_create(hbmpc_ctx* ctx, void** stream_out) {
+    if (!ctx || !stream_out) return InvalidInput;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream_out = s;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream) {
+    if (!ctx || !stream) return InvalidInput;
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);  // the stream's scratch goes with it
+        auto it = ctx->scratch.find((hipStream_t)stream);
+        if (it != ctx->scratch.end()) {
+            (void)hipFree(it->second.first);
+            ctx->scratch.erase(it);
+        }
+    }
+    HIP_TRY(ctx, hipStreamDestroy((hipStream_t)stream));
+    return ShareSuccess;
+}
+
 // ---- HIP graphs ----------------------------------------------------------------------------------
 struct hbmpc_graph {
     hipGraph_t graph = nullptr;

@@ -9,12 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "test_reference_units")
 CBIN = os.path.join(ROOT, "tests", "cpp", "test_c_abi")
+PBIN = os.path.join(ROOT, "tests", "cpp", "test_pipelines")
 
 
 def test_cpp_mirror_builds():
     # host-only g++ compile + link against the in-tree library (no GPU needed)
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
-    assert os.path.exists(BIN) and os.path.exists(CBIN)
+    assert os.path.exists(BIN) and os.path.exists(CBIN) and os.path.exists(PBIN)
 
 
 def test_header_is_plain_c99():
@@ -37,3 +38,11 @@ def test_reference_unit_tests_in_cpp():
     p = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert "all reference unit tests passed" in p.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_pipelines_eager_and_graph():
+    if not os.path.exists(PBIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    p = subprocess.run([PBIN], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "pipelines passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
