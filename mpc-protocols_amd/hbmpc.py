@@ -258,6 +258,16 @@ class Engine:
         return self._f("dev_fr_op")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), C.c_void_p(a_d),
                                       C.c_void_p(b_d), C.c_size_t(N), C.c_void_p(out_d), C.c_void_p(stream))
 
+    def stream_create(self) -> int:
+        st = C.c_void_p()
+        rc = self.L.hbmpc_stream_create(self.ctx, C.byref(st))
+        if rc != 0:
+            raise HbmpcError(f"stream_create -> {rc}: {self.last_error()}")
+        return st.value
+
+    def stream_destroy(self, stream: int):
+        self.L.hbmpc_stream_destroy(self.ctx, C.c_void_p(stream))
+
     # ---- HIP graphs: capture a sequence of dev_* calls once, replay it per refill of the buffers ----
     def graph_begin(self, stream):
         rc = self.L.hbmpc_graph_begin_capture(self.ctx, C.c_void_p(stream))
