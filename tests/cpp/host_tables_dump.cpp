@@ -1,0 +1,54 @@
+// CPU-only dump of the host-side table builders (mpc-protocols_amd/csrc/tables.hpp, host_fr.hpp) for
+// tests/test_host_tables.py, which compares every value with the big-int oracle.  Built with
+// -fsanitize=address,undefined: the table code is the only host arithmetic in the product.
+//   usage: host_tables_dump <fr|gl> <n> <d> <t> <id0,id1,...>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../mpc-protocols_amd/csrc/tables.hpp"
+
+using namespace hbmpc;
+
+template <class H>
+static void put(const char* tag, const H& v) {
+    uint64_t c[4];
+    v.to_canon(c);
+    std::printf("%s %016llx%016llx%016llx%016llx\n", tag, (unsigned long long)c[3], (unsigned long long)c[2], (unsigned long long)c[1],
+                (unsigned long long)c[0]);
+}
+template <class H>
+static int run(size_t n, size_t d, size_t t, const std::vector<size_t>& ids) {
+    const size_t m = d + 1, needed = d + t + 1;
+    H w;
+    if (!domain_omega(domain_size(n), &w)) return 2;
+    put("omega", w);
+    const std::vector<H> el = domain_elements<H>(n, n);
+    for (const H& e : el) put("alpha", e);
+    std::vector<H> xs(m);
+    for (size_t i = 0; i < m; ++i) xs[i] = el[ids[i]];
+    const auto basis = lagrange_basis(xs);  // basis[i][k]
+    for (size_t i = 0; i < m; ++i)
+        for (size_t k = 0; k < m; ++k) put("basis", basis[i][k]);
+    for (size_t s = m; s < needed; ++s)
+        for (size_t i = 0; i < m; ++i) put("verify", horner(basis[i], el[ids[s]]));
+    put("inv7", H::from_u64(7).inv());
+    put("pow", H::from_u64(3).pow_u64(1000003));
+    // the device-constant encodings of one value in every representation it is shipped in
+    std::vector<uint32_t> words;
+    put_const(words, el[n > 1 ? 1 : 0], std::is_same<H, HGl>::value ? IMPL_GOLD : IMPL_U29);
+    std::printf("const");
+    for (uint32_t x : words) std::printf(" %08x", x);
+    std::printf("\n");
+    return 0;
+}
+int main(int argc, char** argv) {
+    if (argc < 6) return 1;
+    const size_t n = std::strtoul(argv[2], nullptr, 10), d = std::strtoul(argv[3], nullptr, 10), t = std::strtoul(argv[4], nullptr, 10);
+    std::vector<size_t> ids;
+    for (char* p = std::strtok(argv[5], ","); p; p = std::strtok(nullptr, ",")) ids.push_back(std::strtoul(p, nullptr, 10));
+    if (ids.size() < d + t + 1) return 1;
+    return std::strcmp(argv[1], "gl") == 0 ? run<HGl>(n, d, t, ids) : run<HFr>(n, d, t, ids);
+}

@@ -1,0 +1,61 @@
+"""The host-side table builders of the product (mpc-protocols_amd/csrc/tables.hpp + host_fr.hpp: domain elements,
+Lagrange bases, verify matrices, inverses -- the only host arithmetic in the library, functions of (n, d, t, ids)
+only) compiled for the CPU with AddressSanitizer + UBSan and compared value by value with the big-int oracle, for
+both fields.  Runs without a GPU."""
+import os
+import subprocess
+
+import pytest
+
+from oracle import spec as SFR
+from oracle.spec_gl import S as SGL
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "host_tables_dump")
+
+
+@pytest.fixture(scope="module")
+def dump():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "host_tables_dump"], stdout=subprocess.DEVNULL)
+
+    def run(field, n, d, t, ids):
+        p = subprocess.run([BIN, field, str(n), str(d), str(t), ",".join(map(str, ids))], capture_output=True, text=True,
+                           timeout=120)
+        assert p.returncode == 0, p.stderr[-2000:]          # ASan / UBSan findings abort with a non-zero code
+        out = {}
+        for line in p.stdout.splitlines():
+            k, _, v = line.partition(" ")
+            out.setdefault(k, []).append(v)
+        return out
+    return run
+
+
+@pytest.mark.parametrize("field", ["fr", "gl"])
+@pytest.mark.parametrize("n,d,t,ids", [(4, 1, 1, [3, 0, 2, 1]), (7, 2, 2, [6, 5, 4, 3, 2]), (16, 5, 5, list(range(16))),
+                                       (16, 10, 5, list(range(16))), (31, 10, 10, list(range(30, -1, -1))),
+                                       (100, 33, 33, list(range(0, 100)))])
+def test_tables_match_oracle(dump, field, n, d, t, ids):
+    S = SFR if field == "fr" else SGL
+    P = S.R_MOD
+    o = dump(field, n, d, t, ids)
+    h = lambda xs: [int(x, 16) for x in xs]  # noqa: E731
+    assert h(o["omega"]) == [S.domain_omega(n)]
+    assert h(o["alpha"]) == [S.domain_element(n, j) for j in range(n)]
+    m, needed = d + 1, d + t + 1
+    xs = [S.domain_element(n, i) for i in ids[:m]]
+    basis = []                                               # coefficients of the Lagrange basis polynomials
+    for i in range(m):
+        ys = [1 if j == i else 0 for j in range(m)]
+        co = S.lagrange_interpolate(xs, ys)
+        basis.append(co + [0] * (m - len(co)))
+    assert h(o["basis"]) == [basis[i][k] for i in range(m) for k in range(m)]
+    want_v = [S.p_eval(basis[i], S.domain_element(n, ids[s])) for s in range(m, needed) for i in range(m)]
+    assert h(o.get("verify", [])) == want_v
+    assert h(o["inv7"]) == [pow(7, -1, P)] and h(o["pow"]) == [pow(3, 1000003, P)]
+    words = [int(w, 16) for w in o["const"][0].split()]
+    a1 = S.domain_element(n, 1 if n > 1 else 0)
+    if field == "gl":                                         # the value itself, two 32-bit words
+        assert words == [a1 & 0xFFFFFFFF, a1 >> 32]
+    else:                                                     # nine 29-bit limbs of a1 * 2^261 mod r (fr_u29.hpp)
+        v = a1 * pow(2, 261, P) % P
+        assert words == [(v >> (29 * i)) & 0x1FFFFFFF for i in range(9)]
