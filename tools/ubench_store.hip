@@ -66,9 +66,33 @@ template <class F> float time_it(F launch, hipStream_t s) {
     hipEventRecord(e1, s); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 50;
 }
+// A with a row stride that is not a power of two (rows of 2^20 elements are 32 MiB apart: do the 16 streams alias
+// onto the same HBM channels?)
+__global__ __launch_bounds__(64) void k_a_strided(uint4* __restrict__ y, size_t G, size_t stride, uint32_t seed) {
+    const size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    uint4 v = make_uint4(seed, threadIdx.x, blockIdx.x, 7);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        uint4* p = y + ((size_t)j * stride + g) * 2;
+        v.x += j;
+        p[0] = v; p[1] = v;
+    }
+}
+__global__ __launch_bounds__(64) void k_rw_strided(const uint4* __restrict__ x, uint4* __restrict__ y, size_t G, size_t stride) {
+    const size_t g0 = (size_t)blockIdx.x * 64;
+    const uint4* src = x + g0 * 12;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const uint4 t = src[i * 64 + threadIdx.x]; acc.x ^= t.x; acc.y += t.y; acc.z ^= t.z; acc.w += t.w; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        acc.x += j;
+        uint4* p = y + ((size_t)j * stride + g0 + threadIdx.x) * 2; p[0] = acc; p[1] = acc;
+    }
+}
 int main() {
     const size_t G = 1 << 20;
-    uint4 *y, *x; CK(hipMalloc(&y, G * N * 32)); CK(hipMalloc(&x, G * 6 * 32)); CK(hipMemset(x, 1, G * 6 * 32));
+    uint4 *y, *x; CK(hipMalloc(&y, (G + 4096) * N * 32)); CK(hipMalloc(&x, G * 6 * 32)); CK(hipMemset(x, 1, G * 6 * 32));
     hipStream_t s; CK(hipStreamCreate(&s));
     const double wb = (double)G * N * 32, rb = (double)G * 6 * 32;
     float ms;
@@ -79,6 +103,12 @@ int main() {
     ms = time_it([&] { hipLaunchKernelGGL(k_c, dim3(G / 256), dim3(256), 0, s, y, G, 1u); }, s);       printf("C  shape A, 256-thread blocks: %7.1f us  %6.0f GB/s write\n", ms * 1e3, wb / ms / 1e6);
     ms = time_it([&] { hipLaunchKernelGGL(k_rw<false>, dim3(G / 64), dim3(64), 0, s, x, y, G); }, s);  printf("RW shape A (read 192B/lane)  : %7.1f us  %6.0f GB/s total\n", ms * 1e3, (wb + rb) / ms / 1e6);
     ms = time_it([&] { hipLaunchKernelGGL(k_rw<true>, dim3(G / 64), dim3(64), 0, s, x, y, G); }, s);   printf("RW shape B                   : %7.1f us  %6.0f GB/s total\n", ms * 1e3, (wb + rb) / ms / 1e6);
+    for (size_t pad : {(size_t)0, (size_t)64, (size_t)192, (size_t)1000, (size_t)4096}) {
+        ms = time_it([&] { hipLaunchKernelGGL(k_a_strided, dim3(G / 64), dim3(64), 0, s, y, G, G + pad, 1u); }, s);
+        printf("A  row stride G + %-5zu       : %7.1f us  %6.0f GB/s write\n", pad, ms * 1e3, wb / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_rw_strided, dim3(G / 64), dim3(64), 0, s, x, y, G, G + pad); }, s);
+        printf("RW row stride G + %-5zu       : %7.1f us  %6.0f GB/s total\n", pad, ms * 1e3, (wb + rb) / ms / 1e6);
+    }
     ms = time_it([&] { hipMemsetAsync(y, 0, G * N * 32, s); }, s);                                      printf("hipMemsetAsync               : %7.1f us  %6.0f GB/s write\n", ms * 1e3, wb / ms / 1e6);
     return 0;
 }
