@@ -249,6 +249,18 @@ def extra_measurements(eng, torch, dev, stream, cref):
                                                summ.data_ptr(), stream, p0=True))
     res["cfg3_decode_p0"] = {"recons_per_s": G / ms * 1e3, "ms": ms,
                              "GBps_algorithmic": (d + t + 1 + 1) * 32 * G / ms / 1e6}
+    # wire codec: the n EvalBatch payloads straight from the party-major encode rows, and back
+    stride = 8 + 32 * G + 24
+    pay = torch.empty((n * stride,), dtype=torch.uint8, device=dev)
+    back = torch.empty_like(y)
+    cst = torch.zeros((n,), dtype=torch.int32, device=dev)
+    ms = ev_time(lambda: eng.dev_pack_fvec(y.data_ptr(), G, G, n, pay.data_ptr(), stride, stream))
+    res["codec_pack_fvec"] = {"ms": ms, "GBps": 2 * 32 * G * n / ms / 1e6, "payloads": n, "elements_each": G}
+    ms = ev_time(lambda: eng.dev_unpack_fvec(pay.data_ptr(), stride, 8 + 32 * G, G, n, back.data_ptr(), G, cst.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert bool((back == y).all()) and int(cst.abs().max()) == 0
+    res["codec_unpack_fvec_validated"] = {"ms": ms, "GBps": 2 * 32 * G * n / ms / 1e6}
+    del pay, back
     # the same decode with the t lowest-id senders corrupted in 1 % of the chunks (flag + OEC/Gao
     # fallback on the device); results must still be the original polynomials
     gen = torch.Generator(device=dev)
