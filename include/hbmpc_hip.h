@@ -111,7 +111,7 @@ ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream);
  * pipeline of hbmpc_dev_* calls is then bound by kernel-launch overhead.  Every hbmpc_dev_* call is capturable
  * once its tables and scratch exist, i.e. after ONE eager run of the same call sequence with the same shapes on
  * the same stream: begin capture, issue the calls again (they only record), end capture, replay the graph as
- * often as the buffers are refilled.  (fpmul for 16 parties x 1024 elements: 1.04 ms eager, 0.27 ms replayed.)
+ * often as the buffers are refilled.  (fpmul for 16 parties x 1024 elements: 0.13 ms eager, 0.08 ms replayed.)
  * stream must be a real stream (not NULL).  A call that would have to build a table or grow scratch during
  * capture fails with HBMPC_NO_DEVICE and invalidates the capture. */
 typedef struct hbmpc_graph hbmpc_graph;
@@ -251,6 +251,20 @@ ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const
 ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open,
                                           size_t m, size_t N, U256* d_out, void* stream);
 
+/* Party-batched forms for hosts that hold the [party][N] arrays of several parties contiguously (every reference test
+ * and bench simulates all n parties in one process): ONE launch for all parties.  Per-party arrays are
+ * [parties][N]; the PUBLIC operands -- the opened values every party shares (opened, d, e, c_open) -- are [N].
+ * triple_local, beaver_open_shares and truncpr_open_share have no public operand: pass N * parties to the plain
+ * entry points.  r_bits is [parties][m][N].  parties in 1..65535. */
+ShareErrorCode hbmpc_dev_triple_finalize_parties(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N, size_t parties,
+                                                 U256* c_out, void* stream);
+ShareErrorCode hbmpc_dev_beaver_finalize_parties(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d,
+                                                 const U256* e, size_t N, size_t parties, U256* z_out, void* stream);
+ShareErrorCode hbmpc_dev_truncpr_rdash_parties(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, size_t parties,
+                                               U256* r_dash_out, void* stream);
+ShareErrorCode hbmpc_dev_truncpr_finalize_parties(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open,
+                                                  size_t m, size_t N, size_t parties, U256* d_out, void* stream);
+
 /* ==== a9: share (+, -, *) share of one party (common/mod.rs:167-300: Add, Sub, share_mul) ====
  * op: 0 = a + b, 1 = a - b, 2 = a * b (element-wise, N elements). */
 ShareErrorCode hbmpc_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out);
@@ -344,6 +358,11 @@ ShareErrorCode hbmpc_gl_beaver_open_shares(hbmpc_ctx* ctx, const uint64_t* a, co
 ShareErrorCode hbmpc_gl_dev_beaver_open_shares(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* x,
                                                const uint64_t* y, size_t N, uint64_t* d_sh_out, uint64_t* e_sh_out,
                                                void* stream);
+ShareErrorCode hbmpc_gl_dev_triple_finalize_parties(hbmpc_ctx* ctx, const uint64_t* rt, const uint64_t* opened, size_t N,
+                                                    size_t parties, uint64_t* c_out, void* stream);
+ShareErrorCode hbmpc_gl_dev_beaver_finalize_parties(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,
+                                                    const uint64_t* d, const uint64_t* e, size_t N, size_t parties,
+                                                    uint64_t* z_out, void* stream);
 ShareErrorCode hbmpc_gl_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,
                                         const uint64_t* d, const uint64_t* e, size_t N, uint64_t* z_out);
 ShareErrorCode hbmpc_gl_dev_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,

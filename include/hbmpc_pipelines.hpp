@@ -11,7 +11,8 @@
 //
 // run() only ENQUEUES on the stream; after one eager run the same call sequence can be captured into a HIP graph
 // (capture()) and replayed (replay()) -- at the batch sizes the protocols really use that removes the launch
-// overhead that dominates (fpmul, 16 parties x 1024 elements: 1.03 ms eager, 0.27 ms replayed).
+// overhead that dominates (fpmul, 16 parties x 1024 elements, party-batched launches: 0.13 ms eager, 0.08 ms
+// replayed; with one launch per party and step it was 1.03 ms / 0.27 ms).
 #pragma once
 #include <stdexcept>
 #include <string>
@@ -107,23 +108,25 @@ class TripleGen : public CapturablePipeline {
         Y_ = arena_.take(n * n * G_);
         Z_ = arena_.take(n * G_);
         opened_ = arena_.take(N);
-        status_ = static_cast<uint8_t*>(arena_.take_bytes(G_));
+        status_ = static_cast<uint8_t*>(arena_.take_bytes(n * G_));
         summ = static_cast<hbmpc_recover_summary*>(arena_.take_bytes(64));
         for (size_t i = 0; i < n; ++i) ids_.push_back(i);
     }
     void run() override {
         const size_t n = n_, N = N_, G = G_, d = 2 * t_;
-        for (size_t p = 0; p < n; ++p)  // [ab - r]_2t = a_i b_i - r2t_i  (triple_generation.rs:333-340), into c as scratch
-            pl_check(hbmpc_dev_triple_local(ctx_, a + p * N, b + p * N, r2t + p * N, N, c + p * N, stream_), ctx_, "triple_local");
+        // [ab - r]_2t = a_i b_i - r2t_i  (triple_generation.rs:333-340), into c as scratch: the [party][N] arrays are
+        // contiguous, so one launch over n N elements serves all parties
+        pl_check(hbmpc_dev_triple_local(ctx_, a, b, r2t, n * N, c, stream_), ctx_, "triple_local");
         for (size_t p = 0; p < n; ++p)  // Vandermonde-encode the chunks of 2t+1 for every recipient (batch_recon.rs:157-165)
             pl_check(hbmpc_dev_vandermonde_apply(ctx_, c + p * N, G, n, d, Y_ + p * n * G, stream_), ctx_, "encode");
-        for (size_t j = 0; j < n; ++j)  // EvalBatch arm: recipient j interpolates its y_j from the senders' rows (stride n G)
-            pl_check(hbmpc_dev_batch_recover_strided(ctx_, ids_.data(), n, Y_ + j * G, n * G, G, n, d, t_, 1, Z_ + j * G, nullptr,
-                                                     status_, summ, stream_), ctx_, "decode y_j");
+        // EvalBatch arm for ALL recipients in one call: with Y[p][j][g] the row of sender p for "chunk" j G + g is
+        // Y + p (n G) + (j G + g), and the output is already Z[j][g]
+        pl_check(hbmpc_dev_batch_recover_strided(ctx_, ids_.data(), n, Y_, n * G, n * G, n, d, t_, 1, Z_, nullptr, status_, summ,
+                                                 stream_), ctx_, "decode y_j");
         // RevealBatch arm: everyone interpolates the 2t+1 opened values per chunk from the n broadcast y_j
         pl_check(hbmpc_dev_batch_recover(ctx_, ids_.data(), n, Z_, G, n, d, t_, opened_, nullptr, status_, summ, stream_), ctx_, "open");
-        for (size_t p = 0; p < n; ++p)  // [c]_t = rt_i + opened  (triple_generation.rs:196-208)
-            pl_check(hbmpc_dev_triple_finalize(ctx_, rt + p * N, opened_, N, c + p * N, stream_), ctx_, "triple_finalize");
+        // [c]_t = rt_i + opened  (triple_generation.rs:196-208), all parties in one launch
+        pl_check(hbmpc_dev_triple_finalize_parties(ctx_, rt, opened_, N, n, c, stream_), ctx_, "triple_finalize");
     }
     U256 *a, *b, *r2t, *rt, *c;  // [party][N]
     hbmpc_recover_summary* summ;
@@ -153,23 +156,15 @@ class FpMul : public CapturablePipeline {
     }
     void run() override {
         const size_t n = n_, N = N_;
-        for (size_t p = 0; p < n; ++p)  // multiplication.rs:417-426
-            pl_check(hbmpc_dev_beaver_open_shares(ctx_, ta + p * N, tb + p * N, x + p * N, y + p * N, N, dsh_ + p * N, esh_ + p * N,
-                                                  stream_), ctx_, "beaver_open_shares");
+        // one launch per step for all parties (the [party][N] arrays are contiguous; opened values are broadcast)
+        pl_check(hbmpc_dev_beaver_open_shares(ctx_, ta, tb, x, y, n * N, dsh_, esh_, stream_), ctx_, "beaver_open_shares");  // multiplication.rs:417-426
         open(dsh_, dop_, "open a-x");  // reconstruct_rbc: per-element recover_secret (:102-139)
         open(esh_, eop_, "open b-y");
-        for (size_t p = 0; p < n; ++p)  // finalize_mul (:57-100)
-            pl_check(hbmpc_dev_beaver_finalize(ctx_, tc + p * N, x + p * N, y + p * N, dop_, eop_, N, z + p * N, stream_), ctx_,
-                     "beaver_finalize");
-        for (size_t p = 0; p < n; ++p) {  // truncpr.rs:277-297
-            pl_check(hbmpc_dev_truncpr_rdash(ctx_, rbits + p * m_ * N, m_, N, rdash_ + p * N, stream_), ctx_, "truncpr_rdash");
-            pl_check(hbmpc_dev_truncpr_open_share(ctx_, z + p * N, rdash_ + p * N, rint + p * N, k_, m_, N, osh_ + p * N, stream_),
-                     ctx_, "truncpr_open_share");
-        }
+        pl_check(hbmpc_dev_beaver_finalize_parties(ctx_, tc, x, y, dop_, eop_, N, n, z, stream_), ctx_, "beaver_finalize");  // :57-100
+        pl_check(hbmpc_dev_truncpr_rdash_parties(ctx_, rbits, m_, N, n, rdash_, stream_), ctx_, "truncpr_rdash");  // truncpr.rs:277-283
+        pl_check(hbmpc_dev_truncpr_open_share(ctx_, z, rdash_, rint, k_, m_, n * N, osh_, stream_), ctx_, "truncpr_open_share");
         open(osh_, cop_, "open b+r");  // truncpr.rs:215
-        for (size_t p = 0; p < n; ++p)  // truncpr.rs:216-220
-            pl_check(hbmpc_dev_truncpr_finalize(ctx_, z + p * N, rdash_ + p * N, cop_, m_, N, out + p * N, stream_), ctx_,
-                     "truncpr_finalize");
+        pl_check(hbmpc_dev_truncpr_finalize_parties(ctx_, z, rdash_, cop_, m_, N, n, out, stream_), ctx_, "truncpr_finalize");  // :216-220
     }
     U256 *x, *y, *ta, *tb, *tc, *rint, *rbits, *z, *out;  // [party][N] (rbits: [party][bit][N])
     hbmpc_recover_summary* summ;

@@ -490,6 +490,29 @@ extern "C" ShareErrorCode hbmpc_gl_make_vandermonde(hbmpc_ctx* ctx, size_t n, si
         HIP_TRY(ctx, hipGetLastError());                                                             \
     } while (0)
 
+// the same with dim3(grid, P): party-batched kernels (blockIdx.y = party)
+#define BY_FIELD_P(P, KERNEL, ...)                                                                   \
+    do {                                                                                             \
+        const dim3 gp(grid, (unsigned)(P));                                                          \
+        if (ctx->impl == IMPL_U29)                                                                   \
+            hipLaunchKernelGGL((KERNEL<U29>), gp, dim3(256), 0, s, __VA_ARGS__);                     \
+        else if (ctx->impl == IMPL_SAT32)                                                            \
+            hipLaunchKernelGGL((KERNEL<Sat32>), gp, dim3(256), 0, s, __VA_ARGS__);                   \
+        else                                                                                         \
+            hipLaunchKernelGGL((KERNEL<Gold>), gp, dim3(256), 0, s, __VA_ARGS__);                    \
+        HIP_TRY(ctx, hipGetLastError());                                                             \
+    } while (0)
+#define BY_IMPL_P(P, KERNEL, ...)                                                                    \
+    do {                                                                                             \
+        const dim3 gp(grid, (unsigned)(P));                                                          \
+        if (ctx->impl == IMPL_U29)                                                                   \
+            hipLaunchKernelGGL((KERNEL<U29>), gp, dim3(256), 0, s, __VA_ARGS__);                     \
+        else                                                                                         \
+            hipLaunchKernelGGL((KERNEL<Sat32>), gp, dim3(256), 0, s, __VA_ARGS__);                   \
+        HIP_TRY(ctx, hipGetLastError());                                                             \
+    } while (0)
+#define CHECK_PARTIES(P) do { if ((P) == 0 || (P) > 65535) return fail(ctx, InvalidInput, "parties must be in 1..65535"); } while (0)
+
 #define BY_FIELD(KERNEL, ...)                                                                        \
     do {                                                                                             \
         if (ctx->impl == IMPL_U29)                                                                   \
@@ -532,9 +555,10 @@ static ShareErrorCode triple_local_any(hbmpc_ctx* ctx, const void* a, const void
     return ShareSuccess;
 }
 static ShareErrorCode triple_finalize_any(hbmpc_ctx* ctx, const void* rt, const void* opened, size_t N, void* c_out,
-                                          void* stream) {
+                                          void* stream, size_t parties = 1) {
     ELEM_PROLOGUE
-    BY_FIELD(k_triple_finalize, W(rt), W(opened), N, WO(c_out));
+    CHECK_PARTIES(parties);
+    BY_FIELD_P(parties, k_triple_finalize, W(rt), W(opened), N, WO(c_out));
     return ShareSuccess;
 }
 static ShareErrorCode beaver_open_any(hbmpc_ctx* ctx, const void* a, const void* b, const void* x, const void* y, size_t N,
@@ -544,10 +568,11 @@ static ShareErrorCode beaver_open_any(hbmpc_ctx* ctx, const void* a, const void*
     return ShareSuccess;
 }
 static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const void* x, const void* y, const void* d,
-                                          const void* e, size_t N, void* z, void* stream) {
+                                          const void* e, size_t N, void* z, void* stream, size_t parties = 1) {
     ELEM_PROLOGUE
+    CHECK_PARTIES(parties);
     const ElemConsts cs = elem_consts(ctx->impl);
-    BY_FIELD(k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z));
+    BY_FIELD_P(parties, k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z));
     return ShareSuccess;
 }
 #define TYPED_PAIR(T, REQ, PFX)                                                                                          \
@@ -578,17 +603,40 @@ static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const v
     }
 TYPED_PAIR(U256, REQ_FR, hbmpc_)
 TYPED_PAIR(uint64_t, REQ_GL, hbmpc_gl_)
-extern "C" ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N,
-                                                  U256* r_dash, void* stream) {
+#define TYPED_PARTIES(T, REQ, PFX)                                                                                       \
+    extern "C" ShareErrorCode PFX##dev_triple_finalize_parties(hbmpc_ctx* ctx, const T* rt, const T* opened, size_t N,   \
+                                                               size_t parties, T* c_out, void* stream) {                 \
+        REQ(ctx);                                                                                                        \
+        return triple_finalize_any(ctx, rt, opened, N, c_out, stream, parties);                                          \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_beaver_finalize_parties(hbmpc_ctx* ctx, const T* c, const T* x, const T* y,       \
+                                                               const T* d, const T* e, size_t N, size_t parties, T* z,   \
+                                                               void* stream) {                                           \
+        REQ(ctx);                                                                                                        \
+        return beaver_finalize_any(ctx, c, x, y, d, e, N, z, stream, parties);                                           \
+    }
+TYPED_PARTIES(U256, REQ_FR, hbmpc_)
+TYPED_PARTIES(uint64_t, REQ_GL, hbmpc_gl_)
+static ShareErrorCode truncpr_rdash_impl(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, size_t parties, U256* r_dash,
+                                         void* stream) {
     REQ_FR(ctx);
     ELEM_PROLOGUE
+    CHECK_PARTIES(parties);
     if (m > 4096) return fail(ctx, InvalidInput, "m beyond the supported range");
     const uint32_t* pow2;
     const int impl = ctx->impl;
     ShareErrorCode rc = get_table(ctx, key("pow2", {m}, impl), [&] { return build_pow2(m, impl); }, &pow2);
     if (rc != ShareSuccess) return rc;
-    BY_IMPL(k_truncpr_rdash, W(r_bits), (int)m, N, pow2, WO(r_dash));
+    BY_IMPL_P(parties, k_truncpr_rdash, W(r_bits), (int)m, N, pow2, WO(r_dash));
     return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N,
+                                                  U256* r_dash, void* stream) {
+    return truncpr_rdash_impl(ctx, r_bits, m, N, 1, r_dash, stream);
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_rdash_parties(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N,
+                                                          size_t parties, U256* r_dash, void* stream) {
+    return truncpr_rdash_impl(ctx, r_bits, m, N, parties, r_dash, stream);
 }
 extern "C" ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
                                                        const U256* r_int, size_t k, size_t m, size_t N, U256* open_out,
@@ -602,17 +650,27 @@ extern "C" ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U25
     BY_IMPL(k_truncpr_open, W(a), W(r_dash), W(r_int), N, cs, WO(open_out));
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
-                                                     const U256* c_open, size_t m, size_t N, U256* d_out,
-                                                     void* stream) {
+static ShareErrorCode truncpr_finalize_impl(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open, size_t m,
+                                            size_t N, size_t parties, U256* d_out, void* stream) {
     REQ_FR(ctx);
     // fpmul/mod.rs:381-406 indexes bytes[m/8] when m % 8 != 0: out of bounds (a panic) from m = 257 on
     if (ctx && m % 8 != 0 && m / 8 >= 32) return fail(ctx, InvalidInput, "m: bytes[m/8] out of bounds in the reference");
     ELEM_PROLOGUE
+    CHECK_PARTIES(parties);
     const HFr inv = HFr::from_u64(2).pow_u64(m).inv();
     const ElemConsts cs = elem_consts(ctx->impl, &inv);
-    BY_IMPL(k_truncpr_finalize, W(a), W(r_dash), W(c_open), (int)(m > 256 ? 256 : m), N, cs, WO(d_out));
+    BY_IMPL_P(parties, k_truncpr_finalize, W(a), W(r_dash), W(c_open), (int)(m > 256 ? 256 : m), N, cs, WO(d_out));
     return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
+                                                     const U256* c_open, size_t m, size_t N, U256* d_out,
+                                                     void* stream) {
+    return truncpr_finalize_impl(ctx, a, r_dash, c_open, m, N, 1, d_out, stream);
+}
+extern "C" ShareErrorCode hbmpc_dev_truncpr_finalize_parties(hbmpc_ctx* ctx, const U256* a, const U256* r_dash,
+                                                             const U256* c_open, size_t m, size_t N, size_t parties,
+                                                             U256* d_out, void* stream) {
+    return truncpr_finalize_impl(ctx, a, r_dash, c_open, m, N, parties, d_out, stream);
 }
 extern "C" ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev, size_t threads, uint32_t iters,
                                                   void* stream) {

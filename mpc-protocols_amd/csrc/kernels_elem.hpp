@@ -18,6 +18,10 @@ struct ElemConsts {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;            \
     if (i >= N) return;
 
+// party-batched launches: blockIdx.y = party; per-party arrays are [party][N] (index ip), public operands -- the
+// opened values every party shares -- are [N] (index i)
+#define HB_PID const size_t ip = (size_t)blockIdx.y * N + i;
+
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
 
 // generic a (+,-,*) b  (common/mod.rs:167-300: share + share, share - share, share_mul)
@@ -54,7 +58,8 @@ __global__ __launch_bounds__(256) void k_triple_finalize(const uint32_t* __restr
                                                          const uint32_t* __restrict__ opened, size_t N,
                                                          uint32_t* __restrict__ out) {
     HB_GID
-    F::store_loose(out + i * F::EW, F::add(F::load(rt + i * F::EW), F::load(opened + i * F::EW)));
+    HB_PID
+    F::store_loose(out + ip * F::EW, F::add(F::load(rt + ip * F::EW), F::load(opened + i * F::EW)));
 }
 // mul/multiplication.rs:417-426:  d_sh = a - x, e_sh = b - y
 template <class F>
@@ -77,12 +82,13 @@ __global__ __launch_bounds__(256) void k_beaver_finalize(const uint32_t* __restr
     const E dv = F::load(d + i * F::EW), ev = F::load(e + i * F::EW);
     const E dm = F::mulc(dv, cs.r2), em = F::mulc(ev, cs.r2);  // Montgomery forms, normalised, < 2r
     const E de = F::mont(ev, dm);                              // d*e
-    const E dy = F::mont(F::load(y + i * F::EW), dm);              // d*[y]
-    const E ex = F::mont(F::load(x + i * F::EW), em);              // e*[x]
-    E acc = F::template sub<4>(F::load(c + i * F::EW), de);
+    HB_PID
+    const E dy = F::mont(F::load(y + ip * F::EW), dm);             // d*[y]
+    const E ex = F::mont(F::load(x + ip * F::EW), em);             // e*[x]
+    E acc = F::template sub<4>(F::load(c + ip * F::EW), de);
     acc = F::template sub<4>(acc, dy);
     acc = F::template sub<4>(acc, ex);  // < 13 r, limbs < 2^29 + 3*2^30
-    F::store_loose(z + i * F::EW, acc);
+    F::store_loose(z + ip * F::EW, acc);
 }
 // fpmul/truncpr.rs:277-283:  r_dash[i] = sum_{j<m} 2^j * r_bits[j][i];  pow2[j] = 2^j device-constant form
 template <class F>
@@ -99,12 +105,13 @@ __global__ __launch_bounds__(256) void k_truncpr_rdash(const uint32_t* __restric
             F::acc_fold(acc);
             pending = 1;
         }
-        F::acc_mac(acc, F::load(r_bits + ((size_t)j * N + i) * F::EW), pow2 + (size_t)j * F::NL);
+        F::acc_mac(acc, F::load(r_bits + (((size_t)blockIdx.y * m + j) * N + i) * F::EW), pow2 + (size_t)j * F::NL);
         ++pending;
     }
     F::acc_fold(acc);
     const E r = F::acc_reduce(acc);
-    F::store_loose(out + i * F::EW, r);
+    HB_PID
+    F::store_loose(out + ip * F::EW, r);
 }
 // truncpr.rs:275,294-297:  open = (a + 2^(k-1)) + (2^m * r_int + r_dash);  cs.c0 = 2^m (const form), cs.c1 = 2^(k-1) limbs
 template <class F>
@@ -146,9 +153,10 @@ __global__ __launch_bounds__(256) void k_truncpr_finalize(const uint32_t* __rest
     } else {
         cm = F::load(tmp);
     }
-    E t = F::template sub<2>(F::load(r_dash + i * F::EW), cm);   // r_dash - c_mod  (= -(c_mod - r_dash)), + 2r
-    t = F::add(t, F::load(a + i * F::EW));                        // a - a'
-    F::store_lt2r(out + i * F::EW, F::mulc(t, cs.c0));
+    HB_PID
+    E t = F::template sub<2>(F::load(r_dash + ip * F::EW), cm);  // r_dash - c_mod  (= -(c_mod - r_dash)), + 2r
+    t = F::add(t, F::load(a + ip * F::EW));                       // a - a'
+    F::store_lt2r(out + ip * F::EW, F::mulc(t, cs.c0));
 }
 
 // register-resident Montgomery-multiply chain: the integer-ALU ceiling of the field implementation

@@ -329,6 +329,12 @@ class Engine:
                [C.c_size_t(N)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
         return getattr(self.L, self._pfx + "dev_" + name)(*args)
 
+    def dev_elem_parties(self, name, ptrs, N, parties, extra=(), stream=0):
+        """party-batched forms (hbmpc_dev_*_parties): per-party arrays [parties][N], public operands [N]"""
+        args = [self.ctx] + [C.c_void_p(p) for p in ptrs[: name_inputs(name)]] + [C.c_size_t(e) for e in extra] + \
+               [C.c_size_t(N), C.c_size_t(parties)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
+        return getattr(self.L, self._pfx + "dev_" + name + "_parties")(*args)
+
     # ---- wire codec ----
     def dev_pack_fvec(self, rows_d, row_stride, G, n_rows, payloads_d, payload_stride_bytes, stream=0):
         return self.L.hbmpc_dev_pack_fvec(self.ctx, C.c_void_p(rows_d), C.c_size_t(row_stride), C.c_size_t(G),

@@ -87,7 +87,7 @@ class TripleGen(_Capturable):
         self.Y = ar.take(n * n * G * U)      # Y[p][j][g]: party p's evaluation for recipient j
         self.Z = ar.take(n * G * U)          # Z[j][g]: recipient j's opened y_j (the broadcast RevealBatch)
         self.opened = ar.take(N * U)         # [G][2t+1] == flat [N]
-        self.status = ar.take(G)
+        self.status = ar.take(n * G)
         self.summ = ar.take(64)
 
     def upload(self, a, b, r2t, rt):
@@ -98,29 +98,25 @@ class TripleGen(_Capturable):
         e, n, t, N, G, m, s = self.eng, self.n, self.t, self.N, self.G, self.m, self.stream
         d = 2 * t
         ids = list(range(n))
-        # 1. every party: [ab - r]_2t = a_i * b_i - r2t_i   (triple_generation.rs:333-340), into c as scratch
-        for p in range(n):
-            o = p * N * U
-            _check(e.dev_elem("triple_local", [self.a + o, self.b + o, self.r2t + o, self.c + o], N, stream=s), e,
-                   "triple_local")
+        # 1. every party: [ab - r]_2t = a_i * b_i - r2t_i   (triple_generation.rs:333-340), into c as scratch; the
+        #    [party][N] arrays are contiguous, so ONE launch over n N elements serves all parties
+        _check(e.dev_elem("triple_local", [self.a, self.b, self.r2t, self.c], n * N, stream=s), e, "triple_local")
         # 2. every party: Vandermonde-encode its chunks of 2t+1 -> y for each recipient (batch_recon.rs:157-165)
         for p in range(n):
             _check(e.dev_vandermonde_apply(self.c + p * N * U, G, n, d, self.Y + p * n * G * U, s), e, "encode")
-        # 3. EvalBatch arm: recipient j interpolates its y_j from the senders' evaluations (needs d+t+1 = 3t+1)
-        for j in range(n):
-            _check(e.dev_batch_recover_strided(ids, self.Y + j * G * U, n * G, G, n, d, t, self.Z + j * G * U, p0=True,
-                                               status_d=self.status, summary_d=self.summ, stream=s), e, "decode y_j")
-            if check:
-                _summary_ok(e, self.summ, f"EvalBatch decode for party {j}", s)
+        # 3. EvalBatch arm: recipient j interpolates its y_j from the senders' evaluations (needs d+t+1 = 3t+1).
+        #    With Y[p][j][g] the row of sender p for "chunk" c = j G + g is Y + p (n G) + c: ONE strided decode over
+        #    n G chunks is all n recipients at once, and its output Z[c] is already Z[j][g].
+        _check(e.dev_batch_recover_strided(ids, self.Y, n * G, n * G, n, d, t, self.Z, p0=True, status_d=self.status,
+                                           summary_d=self.summ, stream=s), e, "decode y_j (all recipients)")
+        if check:
+            _summary_ok(e, self.summ, "EvalBatch decode", s)
         # 4. RevealBatch arm: everyone interpolates the 2t+1 opened values per chunk from the n broadcast y_j
         _check(e.dev_batch_recover(ids, self.Z, G, n, d, t, self.opened, 0, self.status, self.summ, s), e, "decode open")
         if check:
             _summary_ok(e, self.summ, "RevealBatch decode", s)
-        # 5. every party: [c]_t = rt_i + opened   (triple_generation.rs:196-208)
-        for p in range(n):
-            o = p * N * U
-            _check(e.dev_elem("triple_finalize", [self.rt + o, self.opened, self.c + o], N, stream=s), e,
-                   "triple_finalize")
+        # 5. every party: [c]_t = rt_i + opened   (triple_generation.rs:196-208): one party-batched launch
+        _check(e.dev_elem_parties("triple_finalize", [self.rt, self.opened, self.c], N, n, stream=s), e, "triple_finalize")
 
     def download_c(self):
         out = np.zeros((self.n, self.N, 4), dtype=np.uint64)
@@ -165,24 +161,19 @@ class FpMul(_Capturable):
         once tables and scratch exist (after one eager run)."""
         self.check = check
         e, n, N, k, m, s = self.eng, self.n, self.N, self.k, self.m, self.stream
-        o = lambda p: p * N * U  # noqa: E731
-        for p in range(n):   # multiplication.rs:417-426
-            _check(e.dev_elem("beaver_open_shares", [self.ta + o(p), self.tb + o(p), self.x + o(p), self.y + o(p),
-                                                     self.dsh + o(p), self.esh + o(p)], N, stream=s), e, "open shares")
+        # the [party][N] arrays are contiguous: one launch per step for ALL parties (public operands broadcast)
+        _check(e.dev_elem("beaver_open_shares", [self.ta, self.tb, self.x, self.y, self.dsh, self.esh], n * N, stream=s), e,
+               "open shares")                         # multiplication.rs:417-426
         self._open(self.dsh, self.dop, "open a-x")   # reconstruct_rbc: per-element recover_secret (:102-139)
         self._open(self.esh, self.eop, "open b-y")
-        for p in range(n):   # finalize_mul (:57-100)
-            _check(e.dev_elem("beaver_finalize", [self.tc + o(p), self.x + o(p), self.y + o(p), self.dop, self.eop,
-                                                  self.z + o(p)], N, stream=s), e, "beaver_finalize")
-        for p in range(n):   # truncpr.rs:277-297
-            _check(e.dev_elem("truncpr_rdash", [self.rbits + p * m * N * U, self.rdash + o(p)], N, extra=(m,), stream=s),
-                   e, "rdash")
-            _check(e.dev_elem("truncpr_open_share", [self.z + o(p), self.rdash + o(p), self.rint + o(p), self.osh + o(p)],
-                              N, extra=(k, m), stream=s), e, "truncpr open share")
-        self._open(self.osh, self.cop, "open b+r")  # truncpr.rs:215
-        for p in range(n):   # truncpr.rs:216-220
-            _check(e.dev_elem("truncpr_finalize", [self.z + o(p), self.rdash + o(p), self.cop, self.out + o(p)], N,
-                              extra=(m,), stream=s), e, "truncpr finalize")
+        _check(e.dev_elem_parties("beaver_finalize", [self.tc, self.x, self.y, self.dop, self.eop, self.z], N, n, stream=s), e,
+               "beaver_finalize")                     # finalize_mul (:57-100)
+        _check(e.dev_elem_parties("truncpr_rdash", [self.rbits, self.rdash], N, n, extra=(m,), stream=s), e, "rdash")
+        _check(e.dev_elem("truncpr_open_share", [self.z, self.rdash, self.rint, self.osh], n * N, extra=(k, m), stream=s), e,
+               "truncpr open share")                  # truncpr.rs:277-297
+        self._open(self.osh, self.cop, "open b+r")   # truncpr.rs:215
+        _check(e.dev_elem_parties("truncpr_finalize", [self.z, self.rdash, self.cop, self.out], N, n, extra=(m,), stream=s), e,
+               "truncpr finalize")                    # truncpr.rs:216-220
 
     def download(self, which="out"):
         out = np.zeros((self.n, self.N, 4), dtype=np.uint64)
