@@ -140,6 +140,9 @@ ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs_dev, 
 ShareErrorCode hbmpc_vandermonde_apply(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d, U256* y_out);
 ShareErrorCode hbmpc_dev_vandermonde_apply(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
                                            U256* y_out_dev, void* stream);
+/* the encodes of several parties in one launch: x[parties][G][d+1] -> y_out[parties][n][G] (parties in 1..65535) */
+ShareErrorCode hbmpc_dev_vandermonde_apply_parties(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
+                                                   size_t parties, U256* y_out_dev, void* stream);
 /* make_vandermonde alone (common/share/mod.rs:31-45): v_out[n][d+1], host memory. */
 ShareErrorCode hbmpc_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, U256* v_out);
 
@@ -312,6 +315,8 @@ ShareErrorCode hbmpc_gl_dev_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeff
 ShareErrorCode hbmpc_gl_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n, size_t d, uint64_t* y_out);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
                                               uint64_t* y_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_vandermonde_apply_parties(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
+                                                      size_t parties, uint64_t* y_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, uint64_t* v_out);
 ShareErrorCode hbmpc_gl_batch_recover(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals, size_t G,
                                       size_t n, size_t d, size_t t, uint64_t* coeffs_out, uint32_t* ncoeffs_out,

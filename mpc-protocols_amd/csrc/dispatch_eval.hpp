@@ -6,11 +6,15 @@
 
 namespace hbmpc {
 
+// number of independent [G][d+1] -> [n][G] problems of the launch being issued (blockIdx.y); set by the C ABI layer
+// around the launcher calls of one thread (hbmpc_capi.hip)
+extern thread_local unsigned g_eval_parties;
+
 template <class F, int LOG, int CNT>
 inline void launch_fft1_one(const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s) {
     const unsigned grid = (unsigned)((G + EVAL_TILE - 1) / EVAL_TILE);
     const size_t lds = (size_t)EVAL_TILE * (CNT * F::EW + TILE_PAD<F::EW>) * 4;
-    hipLaunchKernelGGL((k_eval_fft1<F, LOG, CNT>), dim3(grid), dim3(EVAL_TILE), lds, s, x, G, n, tw, y);
+    hipLaunchKernelGGL((k_eval_fft1<F, LOG, CNT>), dim3(grid, g_eval_parties), dim3(EVAL_TILE), lds, s, x, G, n, tw, y);
 }
 // cnt in [LO, LO + sizeof...(I))
 template <class F, int LOG, int LO, int... I>
@@ -25,7 +29,7 @@ inline void launch_fftP_one(const uint32_t* x, size_t G, int n, int dp1, int P, 
                             const uint32_t* twist, uint32_t* y, hipStream_t s) {
     const unsigned grid = (unsigned)((G + EVAL_TILE - 1) / EVAL_TILE);
     const size_t lds = (size_t)EVAL_TILE * (dp1 * F::EW + TILE_PAD<F::EW>) * 4;
-    hipLaunchKernelGGL((k_eval_fftP<F, CNT16, FOLD>), dim3(grid), dim3(EVAL_TILE), lds, s, x, G, n, dp1, P, tw16, twist,
+    hipLaunchKernelGGL((k_eval_fftP<F, CNT16, FOLD>), dim3(grid, g_eval_parties), dim3(EVAL_TILE), lds, s, x, G, n, dp1, P, tw16, twist,
                        y);
 }
 template <class F, int LO, int... I>

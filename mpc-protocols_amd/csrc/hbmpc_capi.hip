@@ -142,6 +142,7 @@ static ElemConsts elem_consts(int impl, const HFr* c0 = nullptr, const HFr* c1_p
 }
 
 // ---- context -----------------------------------------------------------------------------------
+namespace hbmpc { thread_local unsigned g_eval_parties = 1; }
 extern "C" const char* hbmpc_version(void) { return "hbmpc-hip 0.1 (gfx950)"; }
 
 extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out) {
@@ -329,8 +330,10 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
     return ShareSuccess;
 }
 
-static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y, void* stream) {
+static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y, void* stream,
+                               size_t parties = 1) {
     if (!ctx) return InvalidInput;
+    if (parties == 0 || parties > 65535) return fail(ctx, InvalidInput, "parties must be in 1..65535");
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");  // :59-64
     if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
     if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
@@ -338,7 +341,9 @@ static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const void* x, size_t G, size_t n
     if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
+    g_eval_parties = (unsigned)parties;  // thread-local: read by the launchers this thread calls next
     ShareErrorCode rc = eval_impl(ctx, (const uint32_t*)x, G, n, d, (uint32_t*)y, s);
+    g_eval_parties = 1;
     if (rc != ShareSuccess) return rc;
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
@@ -353,6 +358,17 @@ extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply(hbmpc_ctx* ctx, const U256
                                                       U256* y_out, void* stream) {
     REQ_FR(ctx);
     return eval_dev(ctx, x, G, n, d, y_out, stream);
+}
+// x[parties][G][d+1] -> y[parties][n][G]: the encodes of several parties in one launch
+extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_parties(hbmpc_ctx* ctx, const U256* x, size_t G, size_t n, size_t d,
+                                                              size_t parties, U256* y_out, void* stream) {
+    REQ_FR(ctx);
+    return eval_dev(ctx, x, G, n, d, y_out, stream, parties);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_parties(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n,
+                                                                 size_t d, size_t parties, uint64_t* y_out, void* stream) {
+    REQ_GL(ctx);
+    return eval_dev(ctx, x, G, n, d, y_out, stream, parties);
 }
 extern "C" ShareErrorCode hbmpc_gl_dev_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs, size_t B, size_t n, size_t d,
                                                       uint64_t* shares_out, void* stream) {

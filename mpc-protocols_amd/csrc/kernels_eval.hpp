@@ -263,6 +263,8 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
+    x += (size_t)blockIdx.y * G * CNT * F::EW;  // party-batched launches: blockIdx.y = party (x[P][G][CNT] -> y[P][n][G])
+    y += (size_t)blockIdx.y * n * G * F::EW;
     stage_tile<CNT * (F::EW >= 4 ? 2 : 1), F::EW>(lds, x, g0, G, CNT, lane);
     __syncthreads();
     const size_t g = g0 + lane;
@@ -292,6 +294,8 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
+    x += (size_t)blockIdx.y * G * dp1 * F::EW;
+    y += (size_t)blockIdx.y * n * G * F::EW;
     stage_tile<(FOLD ? 8 : CNT16) * (F::EW >= 4 ? 2 : 1), F::EW>(lds, x, g0, G, dp1, lane);
     __syncthreads();
     const size_t g = g0 + lane;
@@ -327,6 +331,8 @@ __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict
     using E = typename F::E;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
+    x += (size_t)blockIdx.y * G * dp1 * F::EW;
+    y += (size_t)blockIdx.y * n * G * F::EW;
     const uint32_t* row = x + g * (size_t)dp1 * F::EW;
     for (int j = 0; j < n; ++j) {
         const uint32_t* a = alpha + (size_t)j * F::NL;

@@ -2,12 +2,13 @@
 #include "kernels_eval.hpp"
 #include "launchers.hpp"
 namespace hbmpc {
+extern thread_local unsigned g_eval_parties;
 void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y,
                          hipStream_t s) {
     const unsigned grid = (unsigned)((G + 255) / 256);
-    if (impl == 0) hipLaunchKernelGGL((k_eval_generic<U29>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
-    else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
-    else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    if (impl == 0) hipLaunchKernelGGL((k_eval_generic<U29>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
 }
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s) {
     if (impl == 0) {

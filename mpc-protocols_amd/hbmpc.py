@@ -302,6 +302,10 @@ class Engine:
         return self._f("dev_vandermonde_apply")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),
                                                   C.c_size_t(d), C.c_void_p(y_d), C.c_void_p(stream))
 
+    def dev_vandermonde_apply_parties(self, x_d, G, n, d, parties, y_d, stream=0):
+        return self._f("dev_vandermonde_apply_parties")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
+                                                        C.c_size_t(parties), C.c_void_p(y_d), C.c_void_p(stream))
+
     def dev_batch_recover(self, sender_ids, evals_d, G, n, d, t, out_d, nco_d=0, status_d=0, summary_d=0, stream=0,
                           p0=False):
         ids = _sz(sender_ids)

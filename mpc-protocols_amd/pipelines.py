@@ -102,8 +102,8 @@ class TripleGen(_Capturable):
         #    [party][N] arrays are contiguous, so ONE launch over n N elements serves all parties
         _check(e.dev_elem("triple_local", [self.a, self.b, self.r2t, self.c], n * N, stream=s), e, "triple_local")
         # 2. every party: Vandermonde-encode its chunks of 2t+1 -> y for each recipient (batch_recon.rs:157-165)
-        for p in range(n):
-            _check(e.dev_vandermonde_apply(self.c + p * N * U, G, n, d, self.Y + p * n * G * U, s), e, "encode")
+        #    c[party][G][2t+1] -> Y[party][n][G], all parties in one launch
+        _check(e.dev_vandermonde_apply_parties(self.c, G, n, d, n, self.Y, s), e, "encode")
         # 3. EvalBatch arm: recipient j interpolates its y_j from the senders' evaluations (needs d+t+1 = 3t+1).
         #    With Y[p][j][g] the row of sender p for "chunk" c = j G + g is Y + p (n G) + c: ONE strided decode over
         #    n G chunks is all n recipients at once, and its output Z[c] is already Z[j][g].
