@@ -35,6 +35,19 @@ struct RecoverArgs {
     uint32_t* counters;      // [0] = number of flagged chunks
 };
 
+// The row permutation reaches the device through the arguments of a one-block kernel, which also does the
+// per-call initialisation: counters[0..4) = 0, summary = {0, 0, 0xffffffff, 0}.  (S <= n <= 255.)
+struct RowsArg {
+    uint8_t r[256];
+};
+__global__ inline void k_store_rows(RowsArg a, int* __restrict__ dst, int S, uint32_t* __restrict__ counters,
+                                    uint32_t* __restrict__ summary) {
+    const int i = threadIdx.x;
+    if (i < S) dst[i] = a.r[i];
+    if (i < 4) counters[i] = 0;  // [0] = flagged count ([4..8) may be the local summary)
+    if (i < 4) summary[i] = i == 2 ? 0xffffffffu : 0u;
+}
+
 template <class F>
 HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
     const unsigned long long mask = __ballot(bad);

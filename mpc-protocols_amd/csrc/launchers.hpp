@@ -42,6 +42,7 @@ bool launch_recover_b(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipS
 bool launch_recover_c(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s);
 // OEC / Gao, matvec
 void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);

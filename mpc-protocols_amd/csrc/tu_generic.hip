@@ -22,6 +22,9 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
         else hipLaunchKernelGGL((k_batch_recover_generic<Gold, false>), dim3(grid), dim3(256), 0, s, ra);
     }
 }
+void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s) {
+    hipLaunchKernelGGL(k_store_rows, dim3(1), dim3(256), 0, s, rows, dst, S, counters, summary);
+}
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s) {
     const unsigned grid = (unsigned)((S + 255) / 256);
     if (impl == 0) hipLaunchKernelGGL((k_matvec<U29>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
