@@ -143,17 +143,33 @@ inline std::vector<std::vector<H>> lagrange_basis(const std::vector<H>& xs) {
         A[0] = A[0] * nx;
         ++deg;
     }
+    // denominators A'(x_i) = prod_{j != i} (x_i - x_j), inverted all at once (Montgomery's trick: one field inversion
+    // per basis instead of one per point -- a Fermat inversion is ~380 multiplications, and the OEC tables need a
+    // basis per round)
+    std::vector<H> den(m), pre(m), inv(m);
+    for (size_t i = 0; i < m; ++i) {
+        H dd = H::one();
+        for (size_t j = 0; j < m; ++j)
+            if (j != i) dd = dd * (xs[i] - xs[j]);
+        den[i] = dd;
+    }
+    H run = H::one();
+    for (size_t i = 0; i < m; ++i) {
+        pre[i] = run;
+        run = run * den[i];
+    }
+    H all = run.inv();
+    for (size_t i = m; i-- > 0;) {
+        inv[i] = all * pre[i];
+        all = all * den[i];
+    }
     std::vector<std::vector<H>> basis(m, std::vector<H>(m, H::zero()));
+    std::vector<H> q(m);
     for (size_t i = 0; i < m; ++i) {
         // synthetic division of A by (x - x_i): q[m-1] = A[m], q[k-1] = A[k] + x_i q[k]
-        std::vector<H> q(m);
         q[m - 1] = A[m];
         for (size_t k = m - 1; k > 0; --k) q[k - 1] = A[k] + xs[i] * q[k];
-        H denom = H::one();  // A'(x_i) = prod_{j != i} (x_i - x_j)
-        for (size_t j = 0; j < m; ++j)
-            if (j != i) denom = denom * (xs[i] - xs[j]);
-        const H inv = denom.inv();
-        for (size_t k = 0; k < m; ++k) basis[i][k] = q[k] * inv;
+        for (size_t k = 0; k < m; ++k) basis[i][k] = q[k] * inv[i];
     }
     return basis;
 }
