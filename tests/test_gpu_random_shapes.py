@@ -104,3 +104,61 @@ def test_random_encode_decode(engines, field, seed):
             any_fail = True
             assert st[g] == e.code, (n, t, d, g, st[g], e.code)
     assert (rc != 0) == any_fail
+
+
+@pytest.mark.parametrize("field", ["fr", "goldilocks"])
+def test_argument_validation_fuzz(engines, field):
+    """Random mostly-INVALID arguments: the error code (and so the validation order) must be the oracle's, i.e. the
+    reference's (robust_interpolate.rs:94-157 and :284-341, shamir.rs:199-239)."""
+    eng, S = engines[field], (SFR if field == "fr" else SGL)
+    P = S.R_MOD
+    rng = random.Random(20240 if field == "fr" else 20241)
+    seen = set()
+    for _ in range(150):
+        n = rng.randint(1, 12)
+        t = rng.randint(0, 4)
+        d = rng.randint(0, 5)
+        S_cnt = rng.randint(0, n + 2)
+        ids = [rng.randint(0, n + 1) if rng.random() < 0.15 else rng.randrange(max(n, 1)) for _ in range(S_cnt)]
+        if rng.random() < 0.6 and S_cnt <= n:
+            ids = rng.sample(range(n), S_cnt)                 # mostly distinct, in range
+        degs = [d if rng.random() < 0.9 else d + 1 for _ in range(S_cnt)]
+        poly = [rng.randrange(P) for _ in range(d + 1)]
+        vals = [S.p_eval(poly, S.domain_element(max(n, 1), i % max(n, 1))) for i in ids]
+        # --- RobustShare::recover_secret
+        if S_cnt:
+            try:
+                S.recover_secret([S.Share(v, i, dg) for v, i, dg in zip(vals, ids, degs)], n, t)
+                want = 0
+            except S.ShareErr as e:
+                want = e.code
+            except (IndexError, ZeroDivisionError, ValueError):
+                want = None                                    # the reference would panic: unspecified here
+            if want is not None:
+                rc = eng.recover_secret(ids, degs, to_arr(field, vals), n, t)[0]
+                assert rc == want, ("recover_secret", n, t, d, ids, degs, rc, want)
+                seen.add(("rs", want))
+        # --- batch_recover_secret (two chunks)
+        ev = [(i, [v, (v + 1) % P]) for i, v in zip(ids, vals)]
+        try:
+            S.batch_recover_secret(ev, n, d, t)
+            want = 0
+        except S.ShareErr as e:
+            want = e.code
+        except (IndexError, ZeroDivisionError, ValueError):
+            want = None
+        if want is not None and S_cnt:
+            arr = to_arr(field, [[v, (v + 1) % P] for v in vals])
+            rc = eng.batch_recover(ids, arr, n, d, t)[0]
+            assert rc == want, ("batch_recover", n, t, d, ids, rc, want)
+            seen.add(("br", want))
+        # --- compute_shares
+        try:
+            S.compute_shares(poly, n, d)
+            want = 0
+        except S.ShareErr as e:
+            want = e.code
+        rc = eng.compute_shares(to_arr(field, [poly]), n, d)[0] if n > 0 else None
+        if rc is not None:
+            assert rc == want, ("compute_shares", n, d, rc, want)
+    assert len(seen) >= 4, seen                                # several distinct outcomes were actually exercised
