@@ -292,6 +292,18 @@ def extra_measurements(eng, torch, dev, stream, cref):
     res["triple_local"] = {"elems_per_s": N / ms * 1e3, "ms": ms, "GBps_algorithmic": 128 * N / ms / 1e6,
                            "hbm_frac": 128 * N / ms / 1e6 / HBM_PEAK_GBS}
     del a, b, c, o
+    # seeded dealer (include/hbmpc_hip.h, "hbmpc-chacha20-v1"): config 2 with the coefficients drawn on the device
+    n, d, B = 16, 5, 1 << 20
+    sec = torch.from_numpy(cref.fill_random(4, B).view(np.int64)).to(dev)
+    cws = torch.empty((B, d + 1, 4), dtype=torch.int64, device=dev)
+    sh = torch.empty((n, B, 4), dtype=torch.int64, device=dev)
+    seed = bytes(range(32))
+    ms_fill = ev_time(lambda: eng.dev_fill_coeffs(seed, sec.data_ptr(), B, 0, d, cws.data_ptr(), stream))
+    ms = ev_time(lambda: eng.dev_compute_shares_seeded(seed, sec.data_ptr(), B, 0, n, d, cws.data_ptr(), sh.data_ptr(), stream))
+    res["cfg2_seeded"] = {"share_evals_per_s": n * B / ms * 1e3, "ms": ms, "ms_fill_coeffs": ms_fill,
+                          "coeffs_per_s": d * B / ms_fill * 1e3,
+                          "note": "secrets in HBM -> ChaCha20 rejection-sampled coefficients -> shares"}
+    del sec, cws, sh
     res.update(pipeline_measurements(eng, torch, dev, stream, ev_time))
     res.update(goldilocks_measurements(torch, dev, stream, ev_time))
     # integer-ALU ceiling: register-resident modmul chain (2 modmuls per iteration per lane)

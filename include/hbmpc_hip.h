@@ -132,6 +132,31 @@ ShareErrorCode hbmpc_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B
 ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs_dev, size_t B, size_t n, size_t d,
                                         U256* shares_out_dev, void* stream);
 
+/* ---- seeded variant: the random coefficients are drawn ON THE DEVICE ---------------------------------------
+ * Same sharing as above, but coeffs[b][1..=d] come from a keyed stream this library defines, so only the SECRETS
+ * cross the bus (1/(d+1) of the upload of hbmpc_compute_shares) and a device-resident dealer needs no host rng at
+ * all.  Contract "hbmpc-chacha20-v1" (restated in oracle/spec.py::seeded_coefficient, which the parity tests use):
+ *   coefficient k (1 <= k <= d) of polynomial index i = first_index + b is the first candidate < modulus in the
+ *   sequence of ChaCha20 blocks (RFC 8439 block function, 20 rounds; key = seed as eight little-endian words;
+ *   state words 12..15 = (attempt, k, i mod 2^32, i div 2^32)) for attempt = 0, 1, ...; each 64-byte block yields,
+ *   in order, 64/element-bytes little-endian candidates (Fr: two 32-byte integers with bit 255 cleared; Goldilocks:
+ *   eight u64).  Uniform over the field by rejection; coefficients at different (seed, i, k) are independent under
+ *   the usual ChaCha20 PRF assumption.
+ * This is NOT the stream of the reference's rng (DensePolynomial::rand(degree, rng) with the caller's
+ * ark_std/rand generator, robust_interpolate.rs:66-67): a deployment that needs bit-equality with a given Rust rng
+ * keeps drawing on the host and calls hbmpc_compute_shares.  first_index lets a dealer split one seed over several
+ * calls / GPUs without reusing stream positions (rank r of W deals indices [r B, (r+1) B)).
+ * coeffs_ws_dev[B][d+1]: caller-provided workspace that receives the full coefficient rows (row b = secret b, then
+ * the d draws) -- the dealer usually needs them again (e.g. to open or to verify).
+ * Errors: as hbmpc_compute_shares. */
+ShareErrorCode hbmpc_dev_fill_coeffs(hbmpc_ctx* ctx, const uint8_t seed[32], const U256* secrets_dev, size_t B,
+                                     uint64_t first_index, size_t d, U256* coeffs_out_dev, void* stream);
+ShareErrorCode hbmpc_dev_compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed[32], const U256* secrets_dev, size_t B,
+                                               uint64_t first_index, size_t n, size_t d, U256* coeffs_ws_dev,
+                                               U256* shares_out_dev, void* stream);
+ShareErrorCode hbmpc_compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed[32], const U256* secrets, size_t B,
+                                           uint64_t first_index, size_t n, size_t d, U256* shares_out);
+
 /* ==== a4+a5: make_vandermonde + apply_vandermonde ===========================================
  * replaces common/share/mod.rs:31-76 as used by BatchReconNode::init_batch_reconstruct[_many]
  * (batch_recon.rs:114-115,157-165), RanSha (share_gen.rs:415-419) and RanDouSha
@@ -312,6 +337,13 @@ ShareErrorCode hbmpc_gl_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs, s
                                        uint64_t* shares_out);
 ShareErrorCode hbmpc_gl_dev_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs_dev, size_t B, size_t n, size_t d,
                                            uint64_t* shares_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_fill_coeffs(hbmpc_ctx* ctx, const uint8_t seed[32], const uint64_t* secrets_dev, size_t B,
+                                        uint64_t first_index, size_t d, uint64_t* coeffs_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed[32], const uint64_t* secrets_dev,
+                                                  size_t B, uint64_t first_index, size_t n, size_t d,
+                                                  uint64_t* coeffs_ws_dev, uint64_t* shares_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed[32], const uint64_t* secrets, size_t B,
+                                              uint64_t first_index, size_t n, size_t d, uint64_t* shares_out);
 ShareErrorCode hbmpc_gl_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n, size_t d, uint64_t* y_out);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
                                               uint64_t* y_out_dev, void* stream);

@@ -439,6 +439,69 @@ static ShareErrorCode eval_host(hbmpc_ctx* ctx, const void* x, size_t G, size_t 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ShareSuccess;
 }
+// ---- seeded compute_shares: the random coefficients are generated on the device ("hbmpc-chacha20-v1") ---------
+static ShareErrorCode fill_coeffs_dev(hbmpc_ctx* ctx, const uint8_t seed[32], const void* secrets, size_t B,
+                                      uint64_t first_index, size_t d, void* coeffs_out, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!seed) return fail(ctx, InvalidInput, "null seed");
+    if (d > (1u << 20)) return fail(ctx, InvalidInput, "degree beyond the supported range");
+    if (B == 0) return ShareSuccess;
+    if (!secrets || !coeffs_out) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t k[8];
+    memcpy(k, seed, 32);  // little-endian words
+    launch_fill_coeffs((int)(ebytes(ctx) / 4), k, (const uint32_t*)secrets, B, first_index, (int)(d + 1), (uint32_t*)coeffs_out,
+                       pick(ctx, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+static ShareErrorCode compute_shares_seeded_dev(hbmpc_ctx* ctx, const uint8_t seed[32], const void* secrets, size_t B,
+                                                uint64_t first_index, size_t n, size_t d, void* coeffs_ws, void* shares_out,
+                                                void* stream) {
+    if (ctx && n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
+    ShareErrorCode rc = fill_coeffs_dev(ctx, seed, secrets, B, first_index, d, coeffs_ws, stream);
+    if (rc != ShareSuccess) return rc;
+    return eval_dev(ctx, coeffs_ws, B, n, d, shares_out, stream);
+}
+static ShareErrorCode compute_shares_seeded_host(hbmpc_ctx* ctx, const uint8_t seed[32], const void* secrets, size_t B,
+                                                 uint64_t first_index, size_t n, size_t d, void* shares_out) {
+    if (!ctx) return InvalidInput;
+    if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
+    if (B == 0) return ShareSuccess;
+    if (!secrets || !shares_out || !seed) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t eb = ebytes(ctx);
+    DevBuf ds, dc, dy;  // only the SECRETS cross the bus on the way in: 1/(d+1) of what hbmpc_compute_shares uploads
+    HIP_TRY(ctx, ds.alloc(ctx, B * eb));
+    HIP_TRY(ctx, dc.alloc(ctx, B * (d + 1) * eb));
+    HIP_TRY(ctx, dy.alloc(ctx, B * n * eb));
+    HIP_TRY(ctx, hipMemcpyAsync(ds.p, secrets, B * eb, hipMemcpyHostToDevice, ctx->stream));
+    ShareErrorCode rc = compute_shares_seeded_dev(ctx, seed, ds.p, B, first_index, n, d, dc.p, dy.p, nullptr);
+    if (rc != ShareSuccess) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(shares_out, dy.p, B * n * eb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ShareSuccess;
+}
+#define TYPED_SEEDED(T, REQ, PFX)                                                                                          \
+    extern "C" ShareErrorCode PFX##dev_fill_coeffs(hbmpc_ctx* ctx, const uint8_t seed[32], const T* secrets_dev, size_t B,  \
+                                                   uint64_t first_index, size_t d, T* coeffs_out_dev, void* stream) {       \
+        REQ(ctx);                                                                                                          \
+        return fill_coeffs_dev(ctx, seed, secrets_dev, B, first_index, d, coeffs_out_dev, stream);                         \
+    }                                                                                                                      \
+    extern "C" ShareErrorCode PFX##dev_compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed[32], const T* secrets_dev, \
+                                                             size_t B, uint64_t first_index, size_t n, size_t d,           \
+                                                             T* coeffs_ws_dev, T* shares_out_dev, void* stream) {          \
+        REQ(ctx);                                                                                                          \
+        return compute_shares_seeded_dev(ctx, seed, secrets_dev, B, first_index, n, d, coeffs_ws_dev, shares_out_dev, stream); \
+    }                                                                                                                      \
+    extern "C" ShareErrorCode PFX##compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed[32], const T* secrets, size_t B, \
+                                                         uint64_t first_index, size_t n, size_t d, T* shares_out) {        \
+        REQ(ctx);                                                                                                          \
+        return compute_shares_seeded_host(ctx, seed, secrets, B, first_index, n, d, shares_out);                           \
+    }
+TYPED_SEEDED(U256, REQ_FR, hbmpc_)
+TYPED_SEEDED(uint64_t, REQ_GL, hbmpc_gl_)
+
 extern "C" ShareErrorCode hbmpc_compute_shares(hbmpc_ctx* ctx, const U256* coeffs, size_t B, size_t n, size_t d,
                                                U256* shares_out) {
     REQ_FR(ctx);

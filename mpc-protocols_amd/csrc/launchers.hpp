@@ -49,6 +49,9 @@ void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_gao_gold(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s);
 
+// seeded coefficient generation (kernels_rng.hpp); ew = u32 words per element
+void launch_fill_coeffs(int ew, const uint32_t seed[8], const uint32_t* secrets, size_t B, uint64_t first_index, int dp1,
+                        uint32_t* coeffs, hipStream_t s);
 // wire codec (kernels_codec.hpp)
 void launch_pack_fvec(const uint64_t* rows, size_t row_stride, size_t G, size_t n_rows, uint64_t* payloads,
                       size_t payload_stride_words, hipStream_t s);

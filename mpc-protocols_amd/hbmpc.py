@@ -118,6 +118,16 @@ class Engine:
         rc = self._f("compute_shares")(self.ctx, _p(coeffs), C.c_size_t(B), C.c_size_t(n), C.c_size_t(d), _p(out))
         return rc, out
 
+    def compute_shares_seeded(self, seed, secrets, n, d, first_index=0):
+        """seed: 32 bytes ("hbmpc-chacha20-v1", include/hbmpc_hip.h); secrets: [B] elements"""
+        secrets = np.ascontiguousarray(secrets)
+        B = secrets.shape[0]
+        out = self._new((n, B))
+        seed = (C.c_uint8 * 32).from_buffer_copy(bytes(seed))
+        rc = self._f("compute_shares_seeded")(self.ctx, seed, _p(secrets), C.c_size_t(B), C.c_uint64(first_index),
+                                              C.c_size_t(n), C.c_size_t(d), _p(out))
+        return rc, out
+
     def make_vandermonde(self, n, d):
         out = self._new((n, d + 1))
         rc = self._f("make_vandermonde")(self.ctx, C.c_size_t(n), C.c_size_t(d), _p(out))
@@ -297,6 +307,17 @@ class Engine:
     def dev_compute_shares(self, coeffs_d, B, n, d, out_d, stream=0):
         return self._f("dev_compute_shares")(self.ctx, C.c_void_p(coeffs_d), C.c_size_t(B), C.c_size_t(n),
                                                C.c_size_t(d), C.c_void_p(out_d), C.c_void_p(stream))
+
+    def dev_fill_coeffs(self, seed, secrets_d, B, first_index, d, coeffs_d, stream=0):
+        seed = (C.c_uint8 * 32).from_buffer_copy(bytes(seed))
+        return self._f("dev_fill_coeffs")(self.ctx, seed, C.c_void_p(secrets_d), C.c_size_t(B), C.c_uint64(first_index),
+                                          C.c_size_t(d), C.c_void_p(coeffs_d), C.c_void_p(stream))
+
+    def dev_compute_shares_seeded(self, seed, secrets_d, B, first_index, n, d, coeffs_ws_d, out_d, stream=0):
+        seed = (C.c_uint8 * 32).from_buffer_copy(bytes(seed))
+        return self._f("dev_compute_shares_seeded")(self.ctx, seed, C.c_void_p(secrets_d), C.c_size_t(B),
+                                                    C.c_uint64(first_index), C.c_size_t(n), C.c_size_t(d),
+                                                    C.c_void_p(coeffs_ws_d), C.c_void_p(out_d), C.c_void_p(stream))
 
     def dev_vandermonde_apply(self, x_d, G, n, d, y_d, stream=0):
         return self._f("dev_vandermonde_apply")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),

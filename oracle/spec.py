@@ -589,3 +589,52 @@ class SplitMix64:
 
     def fr(self):
         return from_limbs([self.next() for _ in range(4)]) % R_MOD
+
+
+# ---------------------------------------------------------------------------------------------
+# Seeded coefficient generation (this library's own contract, "hbmpc-chacha20-v1"; NOT a restatement of the
+# reference: there the caller's `rng: &mut impl Rng` supplies DensePolynomial::rand, robust_interpolate.rs:68).
+# The random coefficient k (1 <= k <= degree) of secret number b is a function of (seed, b, k) only, so any
+# number of devices / lanes produce the same polynomial:
+#   ChaCha20 (20 rounds, the original 64-bit-counter / 64-bit-nonce layout), key = the 32-byte seed,
+#   nonce = b, block counter = (k << 32) + attempt;  a 64-byte block is read as little-endian candidates of
+#   ELEM_BYTES bytes each (32 for Fr with bit 255 cleared, 8 for Goldilocks); the first candidate < modulus over
+#   attempt = 0, 1, ... is the coefficient.
+# ---------------------------------------------------------------------------------------------
+def _chacha20_block(key_words, counter, nonce):
+    def rotl(v, c):
+        return ((v << c) & 0xFFFFFFFF) | (v >> (32 - c))
+
+    def qr(s, a, b, c, d):
+        s[a] = (s[a] + s[b]) & 0xFFFFFFFF; s[d] = rotl(s[d] ^ s[a], 16)
+        s[c] = (s[c] + s[d]) & 0xFFFFFFFF; s[b] = rotl(s[b] ^ s[c], 12)
+        s[a] = (s[a] + s[b]) & 0xFFFFFFFF; s[d] = rotl(s[d] ^ s[a], 8)
+        s[c] = (s[c] + s[d]) & 0xFFFFFFFF; s[b] = rotl(s[b] ^ s[c], 7)
+
+    init = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + \
+           [counter & 0xFFFFFFFF, counter >> 32, nonce & 0xFFFFFFFF, nonce >> 32]
+    s = list(init)
+    for _ in range(10):
+        qr(s, 0, 4, 8, 12); qr(s, 1, 5, 9, 13); qr(s, 2, 6, 10, 14); qr(s, 3, 7, 11, 15)
+        qr(s, 0, 5, 10, 15); qr(s, 1, 6, 11, 12); qr(s, 2, 7, 8, 13); qr(s, 3, 4, 9, 14)
+    return [(x + y) & 0xFFFFFFFF for x, y in zip(s, init)]
+
+
+def seeded_coefficient(seed_words, b: int, k: int) -> int:
+    """seed_words: eight u32 (the 32-byte seed, little-endian words)"""
+    ebytes = 32 if R_MOD.bit_length() > 64 else 8
+    attempt = 0
+    while True:
+        blk = _chacha20_block(seed_words, (k << 32) + attempt, b)
+        raw = b"".join(w.to_bytes(4, "little") for w in blk)
+        for c in range(64 // ebytes):
+            v = int.from_bytes(raw[c * ebytes:(c + 1) * ebytes], "little")
+            if ebytes == 32:
+                v &= (1 << 255) - 1
+            if v < R_MOD:
+                return v
+        attempt += 1
+
+
+def seeded_polynomial(seed_words, b: int, secret: int, degree: int):
+    return [secret % R_MOD] + [seeded_coefficient(seed_words, b, k) for k in range(1, degree + 1)]

@@ -15,3 +15,9 @@ for lg in (14, 17, 20):
     dt = (time.perf_counter() - t0) / reps
     by = (d + 1 + n) * 32 * B
     print(f"host API compute_shares B=2^{lg}: {dt*1e3:.2f} ms  {n*B/dt:.3e} share-evals/s  {by/dt/1e9:.1f} GB/s over the boundary (incl. numpy output allocation)")
+    eng.compute_shares_seeded(bytes(32), x[:1024, 0], n, d)
+    sec = np.ascontiguousarray(x[:, 0])
+    t0 = time.perf_counter()
+    for _ in range(reps): rc, y = eng.compute_shares_seeded(bytes(32), sec, n, d)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"host API compute_shares_seeded B=2^{lg}: {dt*1e3:.2f} ms  {n*B/dt:.3e} share-evals/s (uploads the secrets only)")
