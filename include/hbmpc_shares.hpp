@@ -72,6 +72,7 @@ struct FrTraits {  // ark_bls12_381::Fr <-> U256 (ffi/c_bindings/mod.rs:37-49)
     static bool is_zero(const repr& v) { return (v.data[0] | v.data[1] | v.data[2] | v.data[3]) == 0; }
     static bool eq(const repr& a, const repr& b) { return std::memcmp(a.data, b.data, 32) == 0; }
     static constexpr auto compute_shares = hbmpc_compute_shares;
+    static constexpr auto compute_shares_seeded = hbmpc_compute_shares_seeded;
     static constexpr auto make_vandermonde = hbmpc_make_vandermonde;
     static constexpr auto batch_recover = hbmpc_batch_recover;
     static constexpr auto recover_secret = hbmpc_recover_secret;
@@ -89,6 +90,7 @@ struct GlTraits {  // GoldilocksField = Fp64 <-> u64 (common/math/goldilocks.rs:
     static bool is_zero(const repr& v) { return v == 0; }
     static bool eq(const repr& a, const repr& b) { return a == b; }
     static constexpr auto compute_shares = hbmpc_gl_compute_shares;
+    static constexpr auto compute_shares_seeded = hbmpc_gl_compute_shares_seeded;
     static constexpr auto make_vandermonde = hbmpc_gl_make_vandermonde;
     static constexpr auto batch_recover = hbmpc_gl_batch_recover;
     static constexpr auto recover_secret = hbmpc_gl_recover_secret;
@@ -178,6 +180,26 @@ struct Scheme {
         return Result<V>::ok(std::move(shares));
     }
 
+    // B sharings in one call with the random coefficients drawn on the device from `seed` (contract
+    // "hbmpc-chacha20-v1", hbmpc_hip.h) -- for dealers that do not need the draws of a particular host rng.
+    // Result [party j][secret b].  first_index keeps stream positions disjoint when one seed serves several calls.
+    template <class P>
+    static Result<std::vector<std::vector<ShamirShare<P>>>> compute_shares_seeded_impl(const std::vector<F>& secrets, size_t n,
+                                                                                       size_t degree, const uint8_t (&seed)[32],
+                                                                                       uint64_t first_index) {
+        using V = std::vector<std::vector<ShamirShare<P>>>;
+        if (n <= degree) return Result<V>::err(InvalidInput);
+        const size_t B = secrets.size();
+        std::vector<repr> sec(B), out(n * B);
+        for (size_t b = 0; b < B; ++b) sec[b] = secrets[b].v;
+        const ShareErrorCode rc = FT::compute_shares_seeded(FT::context(), seed, sec.data(), B, first_index, n, degree, out.data());
+        if (rc != ShareSuccess) return Result<V>::err(rc);
+        V shares(n);
+        for (size_t j = 0; j < n; ++j)
+            for (size_t b = 0; b < B; ++b) shares[j].emplace_back(F(out[j * B + b]), j, degree);
+        return Result<V>::ok(std::move(shares));
+    }
+
     using Recovered = std::pair<std::vector<F>, F>;  // (coefficients normalised like DensePolynomial, P(0))
 
     template <class P, class Fn>
@@ -207,6 +229,11 @@ struct Scheme {
         static Result<std::vector<ShamirShare<Robust>>> compute_shares(const F& secret, size_t n, size_t degree,
                                                                        const std::vector<size_t>* /*ids*/, Rng& rng) {
             return compute_shares_impl<Robust>(secret, n, degree, rng);
+        }
+        static Result<std::vector<std::vector<ShamirShare<Robust>>>> compute_shares_seeded(const std::vector<F>& secrets, size_t n,
+                                                                                           size_t degree, const uint8_t (&seed)[32],
+                                                                                           uint64_t first_index = 0) {
+            return compute_shares_seeded_impl<Robust>(secrets, n, degree, seed, first_index);
         }
         // SecretSharingScheme::recover_secret (robust_interpolate.rs:94-157)
         static Result<Recovered> recover_secret(const std::vector<ShamirShare<Robust>>& shares, size_t n, size_t t) {

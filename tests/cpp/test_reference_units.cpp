@@ -343,6 +343,41 @@ static void generic_share_recover_and_operators() {
     ns.pop_back();
     CHECK(S::NonRobustShare::recover_secret(ns, 6, 0).unwrap_err() == InsufficientShares);
 }
+// seeded dealer: sharings of many secrets in one call with device-drawn coefficients ("hbmpc-chacha20-v1")
+template <class S>
+static void generic_seeded_sharing() {
+    using F = typename S::F;
+    using RSh = typename S::template ShamirShare<Robust>;
+    const size_t n = 13, t = 4, B = 40;
+    uint8_t seed[32], other[32];
+    for (int i = 0; i < 32; ++i) seed[i] = (uint8_t)(3 * i + 1), other[i] = (uint8_t)(5 * i + 2);
+    std::vector<F> secrets;
+    for (size_t b = 0; b < B; ++b) secrets.push_back(F::from(1000 + 17 * b));
+    auto sh = S::RobustShare::compute_shares_seeded(secrets, n, t, seed).unwrap();
+    CHECK(sh.size() == n && sh[0].size() == B && sh[5][7].id == 5 && sh[5][7].degree == t);
+    for (size_t b = 0; b < B; b += 7) {  // every column opens to its secret, with t lies corrected
+        std::vector<RSh> col;
+        for (size_t j = 0; j < n; ++j) col.push_back(sh[j][b]);
+        for (size_t i = 0; i < t; ++i) col[3 * i].share += F::from(9 + i);
+        auto rec = S::RobustShare::recover_secret(col, n, t).unwrap();
+        CHECK(rec.second == secrets[b] && rec.first.size() == t + 1 && !(rec.first[t] == F::zero()));
+    }
+    // a function of (seed, index) only: same call -> same shares; the index window can be split over calls;
+    // another seed or another index -> other coefficients
+    auto again = S::RobustShare::compute_shares_seeded(secrets, n, t, seed).unwrap();
+    std::vector<F> tail(secrets.begin() + 10, secrets.end());
+    auto split = S::RobustShare::compute_shares_seeded(tail, n, t, seed, 10).unwrap();
+    auto shifted = S::RobustShare::compute_shares_seeded(secrets, n, t, seed, 1).unwrap();
+    auto reseeded = S::RobustShare::compute_shares_seeded(secrets, n, t, other).unwrap();
+    for (size_t j = 0; j < n; ++j)
+        for (size_t b = 0; b < B; ++b) {
+            CHECK(again[j][b].share == sh[j][b].share);
+            if (b >= 10) CHECK(split[j][b - 10].share == sh[j][b].share);
+            if (j) CHECK(!(shifted[j][b].share == sh[j][b].share) && !(reseeded[j][b].share == sh[j][b].share));
+        }
+    CHECK(S::RobustShare::compute_shares_seeded(secrets, 4, 4, seed).unwrap_err() == InvalidInput);
+}
+
 template <class S>
 static void generic_vandermonde_and_batch_recover() {
     using F = typename S::F;
@@ -414,6 +449,8 @@ int main() {
     RUN(generic_share_recover_and_operators<GlScheme>);
     RUN(generic_vandermonde_and_batch_recover<FrScheme>);
     RUN(generic_vandermonde_and_batch_recover<GlScheme>);
+    RUN(generic_seeded_sharing<FrScheme>);
+    RUN(generic_seeded_sharing<GlScheme>);
     std::printf(g_failed ? "%d CHECKS FAILED\n" : "all reference unit tests passed (%d failures)\n", g_failed);
     return g_failed ? 1 : 0;
 }
