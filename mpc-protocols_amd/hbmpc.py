@@ -111,10 +111,11 @@ class Engine:
         assert self.L.hbmpc_set_force_generic(self.ctx, C.c_int(1 if on else 0)) == 0
 
     # ---- host-pointer API ----
-    def compute_shares(self, coeffs, n, d):
+    def compute_shares(self, coeffs, n, d, out=None):
         coeffs = np.ascontiguousarray(coeffs)
         B = coeffs.shape[0]
-        out = self._new((n, B))
+        if out is None:  # a fresh array: its first-touch page faults happen inside the call's device-to-host copy
+            out = self._new((n, B))
         rc = self._f("compute_shares")(self.ctx, _p(coeffs), C.c_size_t(B), C.c_size_t(n), C.c_size_t(d), _p(out))
         return rc, out
 
