@@ -410,6 +410,11 @@ ShareErrorCode hbmpc_gl_dev_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, c
 ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
 /* test aid: 1 = route every shape through the generic (runtime-shaped) kernels */
 ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
+/* The device-table cache of a context (twiddles, Vandermonde rows, one Lagrange/verify table and one OEC/Gao table
+ * per sender set) is bounded: at 512 tables everything not referenced by a captured graph is evicted (unlinked now,
+ * freed at the next eviction, so a concurrent call that already looked a table up never loses it).
+ * stats_out = {tables cached, of which pinned by graphs, evicted-but-not-yet-freed, evictions so far}. */
+ShareErrorCode hbmpc_cache_stats(hbmpc_ctx* ctx, size_t stats_out[4]);
 
 /* ---- measurement aid: register-resident Montgomery-multiply loop (integer-ALU ceiling) ------
  * Runs `iters` dependent modmuls in each of `threads` lanes, writes one U256 per lane to out_dev

@@ -27,9 +27,21 @@ struct hbmpc_ctx {
     hipStream_t stream = nullptr;
     std::mutex mu;                                 // guards the table cache, the scratch map and the staging pool
     std::mutex enqueue_mu;                         // keeps multi-launch sequences that share scratch contiguous on a stream
-    std::map<std::string, uint32_t*> tables;       // device-resident constant tables
+    struct Tab {
+        uint32_t* p = nullptr;
+        bool pinned = false;  // referenced by a captured HIP graph: never evicted
+    };
+    struct Scratch {
+        void* p = nullptr;
+        size_t cap = 0;
+        bool pinned = false;  // referenced by a captured HIP graph: never freed before hbmpc_destroy
+    };
+    std::map<std::string, Tab> tables;             // device-resident constant tables
+    std::vector<uint32_t*> retired_tables;         // evicted one flush ago; freed at the next flush (see get_table)
+    std::vector<void*> retired_scratch;            // outgrown scratch that a graph may still reference
+    size_t evictions = 0;                          // flushes of the table cache so far
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
-    std::map<hipStream_t, std::pair<void*, size_t>> scratch;  // per-stream scratch (calls on one stream are ordered)
+    std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
     std::vector<std::pair<void*, size_t>> stage_free;  // device staging buffers of the host-pointer API, kept between calls
     size_t stage_bytes = 0;
 };
@@ -37,6 +49,9 @@ struct hbmpc_ctx {
 // the calling thread's last failure message (hbmpc_last_error): thread-local, so concurrent callers of one
 // context never write the same string
 static thread_local std::string g_err;
+// > 0 while the calling thread is between hbmpc_graph_begin_capture and _end_capture (capture mode is thread-local):
+// tables and scratch it looks up are then pinned for the graph's lifetime, and nothing may be allocated
+static thread_local int g_capturing = 0;
 
 #define HIP_TRY(ctx, call)                                                                              \
     do {                                                                                                \
@@ -66,21 +81,36 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
-        *out = it->second;
+        if (g_capturing) it->second.pinned = true;
+        *out = it->second.p;
         return ShareSuccess;
     }
-    if (ctx->tables.size() >= 512) {  // bound the cache in a long-running node: drop everything (rare)
-        (void)hipDeviceSynchronize();    // tables may be in use by kernels on caller streams
-        for (auto& kv : ctx->tables) (void)hipFree(kv.second);
-        ctx->tables.clear();
-        ctx->layouts.clear();
+    if (g_capturing) return fail(ctx, HBMPC_NO_DEVICE, "a table would have to be built during graph capture: run the call sequence once eagerly first");
+    if (ctx->tables.size() >= 512) {
+        // Bound the cache in a long-running node (every new sender set is a new table).  Eviction is two-phase so
+        // that a concurrent call which has looked a table up but not launched yet never sees it freed: tables
+        // evicted now are only unlinked, and freed at the NEXT flush (>= 512 table builds later), after a device
+        // synchronise for kernels still running on caller streams.  Tables a captured graph references stay.
+        ++ctx->evictions;
+        (void)hipDeviceSynchronize();
+        for (uint32_t* q : ctx->retired_tables) (void)hipFree(q);
+        ctx->retired_tables.clear();
+        for (auto t = ctx->tables.begin(); t != ctx->tables.end();) {
+            if (t->second.pinned) {
+                ++t;
+                continue;
+            }
+            ctx->retired_tables.push_back(t->second.p);
+            ctx->layouts.erase(t->first);
+            t = ctx->tables.erase(t);
+        }
     }
     std::vector<uint32_t> host = build();
     if (host.empty()) host.push_back(0);
     uint32_t* dev = nullptr;
     HIP_TRY(ctx, hipMalloc(&dev, host.size() * 4));
     HIP_TRY(ctx, hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice));
-    ctx->tables[key] = dev;
+    ctx->tables[key].p = dev;
     *out = dev;
     return ShareSuccess;
 }
@@ -92,17 +122,20 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
 static ShareErrorCode get_scratch(hbmpc_ctx* ctx, hipStream_t s, size_t bytes, void** out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto& slot = ctx->scratch[s];
-    if (slot.second < bytes) {
-        if (slot.first) {
+    if (slot.cap < bytes) {
+        if (g_capturing) return fail(ctx, HBMPC_NO_DEVICE, "scratch would have to grow during graph capture: run the call sequence once eagerly first");
+        if (slot.p) {
             HIP_TRY(ctx, hipStreamSynchronize(s));
-            HIP_TRY(ctx, hipFree(slot.first));
-            slot = {nullptr, 0};
+            if (slot.pinned) ctx->retired_scratch.push_back(slot.p);  // a graph replays kernels that point into it
+            else HIP_TRY(ctx, hipFree(slot.p));
+            slot = hbmpc_ctx::Scratch();
         }
         const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes + bytes / 2;
-        HIP_TRY(ctx, hipMalloc(&slot.first, want));
-        slot.second = want;
+        HIP_TRY(ctx, hipMalloc(&slot.p, want));
+        slot.cap = want;
     }
-    *out = slot.first;
+    if (g_capturing) slot.pinned = true;
+    *out = slot.p;
     return ShareSuccess;
 }
 static std::string key(const char* kind, std::initializer_list<size_t> v, int impl) {
@@ -171,8 +204,10 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->tables) (void)hipFree(kv.second);
-    for (auto& kv : ctx->scratch) (void)hipFree(kv.second.first);
+    for (auto& kv : ctx->tables) (void)hipFree(kv.second.p);
+    for (uint32_t* q : ctx->retired_tables) (void)hipFree(q);
+    for (auto& kv : ctx->scratch) (void)hipFree(kv.second.p);
+    for (void* q : ctx->retired_scratch) (void)hipFree(q);
     for (auto& b : ctx->stage_free) (void)hipFree(b.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -182,6 +217,14 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
     REQ_FR(ctx);
     ctx->impl = impl;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_cache_stats(hbmpc_ctx* ctx, size_t stats_out[4]) {
+    if (!ctx || !stats_out) return InvalidInput;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    size_t pinned = 0;
+    for (auto& kv : ctx->tables) pinned += kv.second.pinned;
+    stats_out[0] = ctx->tables.size(), stats_out[1] = pinned, stats_out[2] = ctx->retired_tables.size(), stats_out[3] = ctx->evictions;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on) {  // either field
@@ -238,7 +281,8 @@ extern "C" ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream) {
         std::lock_guard<std::mutex> lk(ctx->mu);  // the stream's scratch goes with it
         auto it = ctx->scratch.find((hipStream_t)stream);
         if (it != ctx->scratch.end()) {
-            (void)hipFree(it->second.first);
+            if (it->second.pinned) ctx->retired_scratch.push_back(it->second.p);  // a graph may be replayed elsewhere
+            else (void)hipFree(it->second.p);
             ctx->scratch.erase(it);
         }
     }
@@ -256,12 +300,14 @@ extern "C" ShareErrorCode hbmpc_graph_begin_capture(hbmpc_ctx* ctx, void* stream
     if (!stream) return fail(ctx, InvalidInput, "graph capture needs an explicit stream");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+    ++g_capturing;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_graph_end_capture(hbmpc_ctx* ctx, void* stream, hbmpc_graph** graph_out) {
     if (!ctx || !graph_out) return InvalidInput;
     *graph_out = nullptr;
     if (!stream) return fail(ctx, InvalidInput, "graph capture needs an explicit stream");
+    if (g_capturing > 0) --g_capturing;
     hbmpc_graph* g = new hbmpc_graph();
     hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g->graph);
     if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);

@@ -107,6 +107,11 @@ class Engine:
         rc = self.L.hbmpc_set_field_impl(self.ctx, C.c_int({"u29": 0, "sat32": 1}[impl]))
         assert rc == 0
 
+    def cache_stats(self):
+        out = (C.c_size_t * 4)()
+        assert self.L.hbmpc_cache_stats(self.ctx, out) == 0
+        return dict(zip(("tables", "pinned", "retired", "evictions"), [int(v) for v in out]))
+
     def set_force_generic(self, on: bool):
         assert self.L.hbmpc_set_force_generic(self.ctx, C.c_int(1 if on else 0)) == 0
 
