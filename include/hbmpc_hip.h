@@ -415,6 +415,17 @@ ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
  * freed at the next eviction, so a concurrent call that already looked a table up never loses it).
  * stats_out = {tables cached, of which pinned by graphs, evicted-but-not-yet-freed, evictions so far}. */
 ShareErrorCode hbmpc_cache_stats(hbmpc_ctx* ctx, size_t stats_out[4]);
+/* Host-pointer calls whose inputs + outputs fit 256 KiB stage through pinned host memory mapped into the device
+ * (the kernels read and write it over PCIe: no DMA commands; a one-polynomial hbmpc_recover_secret takes ~45 us
+ * instead of ~110 us).  zero_copy = 0 routes them through device buffers + copies like large calls (A/B aid;
+ * results are identical). */
+ShareErrorCode hbmpc_set_small_call_staging(hbmpc_ctx* ctx, int zero_copy);
+/* batch_recover calls of at most max_chunks chunks (default 8192), and compute_shares / vandermonde_apply calls of
+ * at most max_chunks / 4, run wave-per-chunk kernels (one table row / one evaluation point per lane: the latency of
+ * m products instead of (t + out_width) m, of d multiplications instead of a whole FFT; the chip is not full at
+ * these sizes anyway); larger calls run one lane per chunk.  0 = always one lane per chunk.  Same results either
+ * way (A/B aid). */
+ShareErrorCode hbmpc_set_small_batch_chunks(hbmpc_ctx* ctx, size_t max_chunks);
 
 /* ---- measurement aid: register-resident Montgomery-multiply loop (integer-ALU ceiling) ------
  * Runs `iters` dependent modmuls in each of `threads` lanes, writes one U256 per lane to out_dev

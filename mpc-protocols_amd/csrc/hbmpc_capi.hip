@@ -7,6 +7,7 @@
 #include <array>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -40,6 +41,9 @@ struct hbmpc_ctx {
     std::vector<uint32_t*> retired_tables;         // evicted one flush ago; freed at the next flush (see get_table)
     std::vector<void*> retired_scratch;            // outgrown scratch that a graph may still reference
     size_t evictions = 0;                          // flushes of the table cache so far
+    std::vector<void*> pin_free;                   // pinned, device-mapped staging blocks of small host-pointer calls (Stage)
+    size_t wide_max_chunks = 8192;                 // batch_recover calls up to this many chunks (evaluations: a quarter of it) use the wave-per-chunk kernels
+    bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
     std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
     std::vector<std::pair<void*, size_t>> stage_free;  // device staging buffers of the host-pointer API, kept between calls
@@ -208,6 +212,7 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     for (uint32_t* q : ctx->retired_tables) (void)hipFree(q);
     for (auto& kv : ctx->scratch) (void)hipFree(kv.second.p);
     for (void* q : ctx->retired_scratch) (void)hipFree(q);
+    for (void* q : ctx->pin_free) (void)hipHostFree(q);
     for (auto& b : ctx->stage_free) (void)hipFree(b.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -217,6 +222,11 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
     REQ_FR(ctx);
     ctx->impl = impl;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_small_batch_chunks(hbmpc_ctx* ctx, size_t max_chunks) {
+    if (!ctx) return InvalidInput;
+    ctx->wide_max_chunks = max_chunks;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_cache_stats(hbmpc_ctx* ctx, size_t stats_out[4]) {
@@ -337,6 +347,15 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
     const size_t size = domain_size(n), dp1 = d + 1;
     const int impl = ctx->impl;
     const bool gold = impl == IMPL_GOLD;
+    if (G * g_eval_parties <= ctx->wide_max_chunks / 4 && !ctx->force_generic) {  // small batch: wave per chunk
+        const uint32_t* alpha;
+        ShareErrorCode rc = get_table(ctx, key("alpha", {n}, impl), [&] {
+            return gold ? build_alpha<HGl>(n, impl) : build_alpha<HFr>(n, impl);
+        }, &alpha);
+        if (rc != ShareSuccess) return rc;
+        launch_eval_wide(impl, x, G, (int)n, (int)dp1, alpha, y, s);
+        return ShareSuccess;
+    }
     if ((impl == IMPL_U29 || gold) && size <= 16 && !ctx->force_generic) {
         const uint32_t* tw;
         ShareErrorCode rc = get_table(ctx, key("tw", {size}, impl), [&] {
@@ -468,21 +487,119 @@ struct DevBuf {
     }
 };
 
+
+// ---- staging of one host-pointer call -------------------------------------------------------------------------
+// Large calls: device buffers from the DevBuf pool + async copies on the context stream.  Small calls (everything
+// fits one 256 KiB block) stage through pinned host memory that is mapped into the device: inputs are memcpy'd in,
+// the kernels read and write that block over PCIe, outputs are memcpy'd out after the stream sync -- no DMA commands
+// at all.  On this box one 512-byte hipMemcpy + sync costs 16-27 us and a kernel launch + sync 25 us, so a
+// one-polynomial recover_secret (1 upload, 3 launches, 4 downloads) drops from 111 us to about 45 us
+// (tools/time_small_calls.py).  Only plain loads/stores touch the mapped block (the kernels' atomics -- flag lists,
+// counters -- live in device scratch; the host path derives its summary from the status bytes instead).
+struct Stage {
+    static constexpr size_t BLOCK = 256 << 10;
+    hbmpc_ctx* ctx;
+    bool mapped = false, finished = false;
+    char* hblk = nullptr;  // host view of the block
+    char* dblk = nullptr;  // device view
+    size_t off = 0;
+    std::deque<DevBuf> bufs;
+    struct Out {
+        void* dst;
+        const void* src;
+        size_t bytes;
+    };
+    std::vector<Out> outs;
+
+    Stage(hbmpc_ctx* c, size_t total_bytes, size_t n_bufs) : ctx(c) {
+        if (!c->zero_copy || total_bytes + 256 * n_bufs > BLOCK) return;
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (!c->pin_free.empty()) {
+                hblk = (char*)c->pin_free.back();
+                c->pin_free.pop_back();
+            }
+        }
+        if (!hblk && hipHostMalloc((void**)&hblk, BLOCK, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            hblk = nullptr;
+            return;  // no pinned memory to be had: the device-buffer path serves the call
+        }
+        if (hipHostGetDevicePointer((void**)&dblk, hblk, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(hblk);
+            hblk = nullptr;
+            return;
+        }
+        mapped = true;
+    }
+    ~Stage() {
+        if (!hblk) return;
+        if (!finished) (void)hipStreamSynchronize(ctx->stream);  // an error path: kernels may still be writing the block
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (ctx->pin_free.size() < 16) ctx->pin_free.push_back(hblk);
+        else (void)hipHostFree(hblk);
+    }
+    Stage(const Stage&) = delete;
+    Stage& operator=(const Stage&) = delete;
+
+    hipError_t alloc(size_t bytes, void** p) {
+        if (mapped) {
+            *p = dblk + off;
+            off += (bytes + 255) & ~(size_t)255;
+            return off <= BLOCK ? hipSuccess : hipErrorOutOfMemory;  // cannot happen: sized in the constructor
+        }
+        bufs.emplace_back();
+        hipError_t e = bufs.back().alloc(ctx, bytes);
+        *p = bufs.back().p;
+        return e;
+    }
+    hipError_t in(const void* src, size_t bytes, void** p) {
+        hipError_t e = alloc(bytes, p);
+        if (e != hipSuccess || bytes == 0) return e;
+        if (mapped) {
+            memcpy(hblk + ((char*)*p - dblk), src, bytes);
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(*p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    }
+    hipError_t out(void* dst, const void* p, size_t bytes) {  // p: a pointer returned by alloc()/in()
+        if (!dst || bytes == 0) return hipSuccess;
+        if (mapped) {
+            outs.push_back({dst, hblk + ((const char*)p - dblk), bytes});
+            return hipSuccess;
+        }
+        return hipMemcpyAsync(dst, p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t finish() {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        finished = true;
+        if (e != hipSuccess) return e;
+        for (const Out& o : outs) memcpy(o.dst, o.src, o.bytes);
+        return hipSuccess;
+    }
+};
+extern "C" ShareErrorCode hbmpc_set_small_call_staging(hbmpc_ctx* ctx, int zero_copy) {
+    if (!ctx) return InvalidInput;
+    ctx->zero_copy = zero_copy != 0;
+    return ShareSuccess;
+}
+
 static ShareErrorCode eval_host(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y) {
     if (!ctx) return InvalidInput;
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
     if (G == 0) return ShareSuccess;
     if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    DevBuf dx, dy;
     const size_t eb = ebytes(ctx);
-    HIP_TRY(ctx, dx.alloc(ctx, G * (d + 1) * eb));
-    HIP_TRY(ctx, dy.alloc(ctx, G * n * eb));
-    HIP_TRY(ctx, hipMemcpyAsync(dx.p, x, G * (d + 1) * eb, hipMemcpyHostToDevice, ctx->stream));
-    ShareErrorCode rc = eval_dev(ctx, dx.p, G, n, d, dy.p, nullptr);
+    Stage st(ctx, G * (d + 1 + n) * eb, 2);
+    void *dx, *dy;
+    HIP_TRY(ctx, st.in(x, G * (d + 1) * eb, &dx));
+    HIP_TRY(ctx, st.alloc(G * n * eb, &dy));
+    ShareErrorCode rc = eval_dev(ctx, dx, G, n, d, dy, nullptr);
     if (rc != ShareSuccess) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(y, dy.p, G * n * eb, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, st.out(y, dy, G * n * eb));
+    HIP_TRY(ctx, st.finish());
     return ShareSuccess;
 }
 // ---- seeded compute_shares: the random coefficients are generated on the device ("hbmpc-chacha20-v1") ---------
@@ -517,15 +634,15 @@ static ShareErrorCode compute_shares_seeded_host(hbmpc_ctx* ctx, const uint8_t s
     if (!secrets || !shares_out || !seed) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t eb = ebytes(ctx);
-    DevBuf ds, dc, dy;  // only the SECRETS cross the bus on the way in: 1/(d+1) of what hbmpc_compute_shares uploads
-    HIP_TRY(ctx, ds.alloc(ctx, B * eb));
-    HIP_TRY(ctx, dc.alloc(ctx, B * (d + 1) * eb));
-    HIP_TRY(ctx, dy.alloc(ctx, B * n * eb));
-    HIP_TRY(ctx, hipMemcpyAsync(ds.p, secrets, B * eb, hipMemcpyHostToDevice, ctx->stream));
-    ShareErrorCode rc = compute_shares_seeded_dev(ctx, seed, ds.p, B, first_index, n, d, dc.p, dy.p, nullptr);
+    Stage st(ctx, B * (1 + d + 1 + n) * eb, 3);  // only the SECRETS cross the bus on the way in: 1/(d+1) of what hbmpc_compute_shares uploads
+    void *ds, *dc, *dy;
+    HIP_TRY(ctx, st.in(secrets, B * eb, &ds));
+    HIP_TRY(ctx, st.alloc(B * (d + 1) * eb, &dc));
+    HIP_TRY(ctx, st.alloc(B * n * eb, &dy));
+    ShareErrorCode rc = compute_shares_seeded_dev(ctx, seed, ds, B, first_index, n, d, dc, dy, nullptr);
     if (rc != ShareSuccess) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(shares_out, dy.p, B * n * eb, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, st.out(shares_out, dy, B * n * eb));
+    HIP_TRY(ctx, st.finish());
     return ShareSuccess;
 }
 #define TYPED_SEEDED(T, REQ, PFX)                                                                                          \
@@ -815,32 +932,29 @@ static ShareErrorCode elem_host(hbmpc_ctx* ctx, std::initializer_list<std::pair<
     if (!ctx) return InvalidInput;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t eb = ebytes(ctx);
-    std::vector<DevBuf> bi(ins.size()), bo(outs.size());
+    size_t total = 0;
+    for (auto& in : ins) total += in.second * eb;
+    for (auto& o : outs) total += o.second * eb;
+    Stage st(ctx, total, ins.size() + outs.size());
     std::vector<const void*> pi;
     std::vector<void*> po;
-    size_t k = 0;
     for (auto& in : ins) {
         if (in.second && !in.first) return fail(ctx, InvalidInput, "null buffer");
-        HIP_TRY(ctx, bi[k].alloc(ctx, in.second * eb));
-        HIP_TRY(ctx, hipMemcpyAsync(bi[k].p, in.first, in.second * eb, hipMemcpyHostToDevice, ctx->stream));
-        pi.push_back(bi[k].p);
-        ++k;
+        void* p = nullptr;
+        HIP_TRY(ctx, st.in(in.first, in.second * eb, &p));
+        pi.push_back(p);
     }
-    k = 0;
     for (auto& o : outs) {
         if (o.second && !o.first) return fail(ctx, InvalidInput, "null buffer");
-        HIP_TRY(ctx, bo[k].alloc(ctx, o.second * eb));
-        po.push_back(bo[k].p);
-        ++k;
+        void* p = nullptr;
+        HIP_TRY(ctx, st.alloc(o.second * eb, &p));
+        po.push_back(p);
     }
     ShareErrorCode rc = fn(pi, po);
     if (rc != ShareSuccess) return rc;
-    k = 0;
-    for (auto& o : outs) {
-        HIP_TRY(ctx, hipMemcpyAsync(o.first, bo[k].p, o.second * eb, hipMemcpyDeviceToHost, ctx->stream));
-        ++k;
-    }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t k = 0;
+    for (auto& o : outs) HIP_TRY(ctx, st.out(o.first, po[k++], o.second * eb));
+    HIP_TRY(ctx, st.finish());
     return ShareSuccess;
 }
 typedef std::vector<const void*> VI;

@@ -346,4 +346,28 @@ __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict
     }
 }
 
+// Small batches: one wave per chunk, one lane per evaluation point (Horner over the chunk's d+1 coefficients, which
+// every lane reads from the same addresses).  The latency of d multiplications instead of a whole per-lane FFT; used
+// while the call is too small to fill the chip anyway (see k_batch_recover_wide).  Same results as every other path.
+template <class F>
+__global__ __launch_bounds__(256) void k_eval_wide(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+                                                   const uint32_t* __restrict__ alpha, uint32_t* __restrict__ y) {
+    using E = typename F::E;
+    const int lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    x += (size_t)blockIdx.y * G * dp1 * F::EW;
+    y += (size_t)blockIdx.y * n * G * F::EW;
+    const uint32_t* row = x + g * (size_t)dp1 * F::EW;
+    for (int j = lane; j < n; j += 64) {
+        const uint32_t* a = alpha + (size_t)j * F::NL;
+        E acc = F::load(row + (size_t)(dp1 - 1) * F::EW);
+        for (int k = dp1 - 2; k >= 0; --k) {
+            acc = F::mulc(acc, a);
+            acc = F::add(acc, F::load(row + (size_t)k * F::EW));
+        }
+        F::store_loose(y + ((size_t)j * G + g) * F::EW, acc);
+    }
+}
+
 }  // namespace hbmpc

@@ -10,6 +10,12 @@ void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, 
     else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
     else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
 }
+void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y, hipStream_t s) {
+    const unsigned grid = (unsigned)((G + 3) / 4);
+    if (impl == 0) hipLaunchKernelGGL((k_eval_wide<U29>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    else if (impl == 1) hipLaunchKernelGGL((k_eval_wide<Sat32>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+    else hipLaunchKernelGGL((k_eval_wide<Gold>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y);
+}
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s) {
     if (impl == 0) {
         if (p0) hipLaunchKernelGGL((k_batch_recover_generic<U29, true>), dim3(grid), dim3(256), 0, s, ra);
@@ -20,6 +26,20 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
     } else {
         if (p0) hipLaunchKernelGGL((k_batch_recover_generic<Gold, true>), dim3(grid), dim3(256), 0, s, ra);
         else hipLaunchKernelGGL((k_batch_recover_generic<Gold, false>), dim3(grid), dim3(256), 0, s, ra);
+    }
+}
+void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, hipStream_t s) {
+    const unsigned grid = (unsigned)((ra.G + 3) / 4);
+    const size_t ew = impl == 2 ? 2 : 8, lds = 4 * (size_t)ra.needed * ew * 4;  // one chunk's sender values per wave
+    if (impl == 0) {
+        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<U29, true>), dim3(grid), dim3(256), lds, s, ra);
+        else hipLaunchKernelGGL((k_batch_recover_wide<U29, false>), dim3(grid), dim3(256), lds, s, ra);
+    } else if (impl == 1) {
+        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Sat32, true>), dim3(grid), dim3(256), lds, s, ra);
+        else hipLaunchKernelGGL((k_batch_recover_wide<Sat32, false>), dim3(grid), dim3(256), lds, s, ra);
+    } else {
+        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Gold, true>), dim3(grid), dim3(256), lds, s, ra);
+        else hipLaunchKernelGGL((k_batch_recover_wide<Gold, false>), dim3(grid), dim3(256), lds, s, ra);
     }
 }
 void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s) {

@@ -107,6 +107,12 @@ class Engine:
         rc = self.L.hbmpc_set_field_impl(self.ctx, C.c_int({"u29": 0, "sat32": 1}[impl]))
         assert rc == 0
 
+    def set_small_call_staging(self, zero_copy: bool):
+        assert self.L.hbmpc_set_small_call_staging(self.ctx, C.c_int(1 if zero_copy else 0)) == 0
+
+    def set_small_batch_chunks(self, max_chunks: int):
+        assert self.L.hbmpc_set_small_batch_chunks(self.ctx, C.c_size_t(max_chunks)) == 0
+
     def cache_stats(self):
         out = (C.c_size_t * 4)()
         assert self.L.hbmpc_cache_stats(self.ctx, out) == 0

@@ -23,13 +23,15 @@ def _eng():
     e.close()
 
 
-@pytest.fixture(params=["fast", "generic"])
+@pytest.fixture(params=["fast", "lane", "generic"])
 def eng(request, _eng):
     """fast: the pruned-FFT / register-resident kernels instantiated for Goldilocks; generic: the runtime-shaped
     Horner / re-reading kernels (what shapes outside the templates fall back to)"""
     _eng.set_force_generic(request.param == "generic")
+    _eng.set_small_batch_chunks(0 if request.param == "lane" else 8192)  # lane: the large-batch kernels at every size
     yield _eng
     _eng.set_force_generic(False)
+    _eng.set_small_batch_chunks(8192)
 
 
 def rnd(seed, *shape):

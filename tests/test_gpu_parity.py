@@ -22,14 +22,18 @@ def eng():
     e.close()
 
 
-@pytest.fixture(params=["u29", "u29-generic", "sat32"])
+@pytest.fixture(params=["u29", "u29-lane", "u29-generic", "sat32", "sat32-lane"])
 def eng_all(request, eng):
+    """u29 / sat32: the defaults (small batches decode with the wave-per-chunk kernel); -lane: the lane-per-chunk
+    kernels the large batches use, at every size; -generic: the runtime-shaped kernels"""
     mode = request.param
-    eng.set_impl("sat32" if mode == "sat32" else "u29")
+    eng.set_impl("sat32" if mode.startswith("sat32") else "u29")
     eng.set_force_generic(mode == "u29-generic")
+    eng.set_small_batch_chunks(0 if mode.endswith("-lane") else 8192)
     yield eng
     eng.set_impl("u29")
     eng.set_force_generic(False)
+    eng.set_small_batch_chunks(8192)
 
 
 def rnd(seed, *shape):

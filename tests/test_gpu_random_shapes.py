@@ -70,8 +70,11 @@ def test_random_encode_decode(engines, field, seed):
     for p in polys[:2]:                                       # low-degree / zero polynomials among them
         for k in range(rng.randint(0, d + 1)):
             p[d - k] = 0
+    eng.set_small_batch_chunks(0)                             # the lane-per-chunk (FFT / generic) kernels ...
+    rc0, y0 = eng.vandermonde_apply(to_arr(field, polys), n, d)
+    eng.set_small_batch_chunks(8192)                          # ... and the default wave-per-chunk kernel: same bytes
     rc, y = eng.vandermonde_apply(to_arr(field, polys), n, d)
-    assert rc == 0
+    assert rc == 0 and rc0 == 0 and np.array_equal(y, y0)
     for g in range(min(G, 3)):
         want = [s.v for s in S.compute_shares(polys[g], n, d)] if n > d else None
         assert [to_int(field, y[j, g]) for j in range(n)] == want
@@ -87,7 +90,11 @@ def test_random_encode_decode(engines, field, seed):
         k = 0 if mode == 0 else (rng.randint(1, kmax) if (mode < 3 or n > 40) else rng.randint(t + 1, min(S_cnt, 2 * t + 2)))
         for i in rng.sample(ids, min(k, S_cnt)):
             ev[i][g] = (ev[i][g] + rng.randrange(1, P)) % P
+    eng.set_small_batch_chunks(0)                             # the lane-per-chunk kernels of the large batches ...
+    lane = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
+    eng.set_small_batch_chunks(8192)                          # ... and the default wave-per-chunk kernel: same bytes
     rc, co, nco, st = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
+    assert lane[0] == rc and all(np.array_equal(u, v) for u, v in zip(lane[1:], (co, nco, st)))
     if S_cnt < d + t + 1:                                     # robust_interpolate.rs:333-341: "Not enough evaluations"
         with pytest.raises(S.InvalidInput):
             S.batch_recover_secret([(i, ev[i][:1]) for i in ids], n, d, t)
