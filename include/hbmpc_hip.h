@@ -415,7 +415,7 @@ ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
  * freed at the next eviction, so a concurrent call that already looked a table up never loses it).
  * stats_out = {tables cached, of which pinned by graphs, evicted-but-not-yet-freed, evictions so far}. */
 ShareErrorCode hbmpc_cache_stats(hbmpc_ctx* ctx, size_t stats_out[4]);
-/* Host-pointer calls whose inputs + outputs fit 256 KiB stage through pinned host memory mapped into the device
+/* Host-pointer calls whose inputs + outputs fit 2 MiB stage through pinned host memory mapped into the device
  * (the kernels read and write it over PCIe: no DMA commands; a one-polynomial hbmpc_recover_secret takes ~45 us
  * instead of ~110 us).  zero_copy = 0 routes them through device buffers + copies like large calls (A/B aid;
  * results are identical). */

@@ -490,14 +490,14 @@ struct DevBuf {
 
 // ---- staging of one host-pointer call -------------------------------------------------------------------------
 // Large calls: device buffers from the DevBuf pool + async copies on the context stream.  Small calls (everything
-// fits one 256 KiB block) stage through pinned host memory that is mapped into the device: inputs are memcpy'd in,
+// fits one 2 MiB block) stage through pinned host memory that is mapped into the device: inputs are memcpy'd in,
 // the kernels read and write that block over PCIe, outputs are memcpy'd out after the stream sync -- no DMA commands
 // at all.  On this box one 512-byte hipMemcpy + sync costs 16-27 us and a kernel launch + sync 25 us, so a
 // one-polynomial recover_secret (1 upload, 3 launches, 4 downloads) drops from 111 us to about 45 us
 // (tools/time_small_calls.py).  Only plain loads/stores touch the mapped block (the kernels' atomics -- flag lists,
 // counters -- live in device scratch; the host path derives its summary from the status bytes instead).
 struct Stage {
-    static constexpr size_t BLOCK = 256 << 10;
+    static constexpr size_t BLOCK = 2048 << 10;
     hbmpc_ctx* ctx;
     bool mapped = false, finished = false;
     char* hblk = nullptr;  // host view of the block
