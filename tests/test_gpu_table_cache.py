@@ -77,3 +77,40 @@ def test_graph_survives_cache_eviction():
         assert rc == 0 and np.array_equal(co, x[:8])
     eng.graph_destroy(g)
     eng.close()
+
+
+def test_contexts_release_their_memory():
+    """create -> use (small zero-copy calls, a large staged call, a fallback decode, a stream + scratch) -> destroy,
+    twenty times: the device's free memory must come back (tables, scratch, staging pools, pinned blocks)."""
+    pkg = load_package()
+    n, t, d = 16, 5, 5
+
+    def cycle():
+        eng = pkg.Engine(0)
+        x = cref.fill_random(5, 4096 * (d + 1)).reshape(4096, d + 1, 4)
+        rc, y = eng.compute_shares(x, n, d)                      # large enough for the device-buffer path
+        assert rc == 0
+        rc, y1 = eng.compute_shares(x[:3], n, d)                 # zero-copy path
+        ev = np.ascontiguousarray(y[:, :64])
+        ev[0, 7, 0] ^= np.uint64(1)
+        rc, co, nco, st = eng.batch_recover(list(range(n)), ev, n, d, t)   # fallback: scratch + OEC/Gao tables
+        assert rc == 0 and np.array_equal(co, x[:64]) and st[7] == 1
+        s = eng.stream_create()
+        dx = eng.dev_alloc(x.nbytes)
+        dy = eng.dev_alloc(n * 4096 * 32)
+        eng.h2d(dx, x, s)
+        assert eng.dev_compute_shares(dx, 4096, n, d, dy, s) == 0
+        eng.sync(s)
+        eng.dev_free(dx)
+        eng.dev_free(dy)
+        eng.stream_destroy(s)
+        eng.close()
+
+    cycle()  # first use: runtime-internal allocations (code objects, queues) happen once
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), (free0, free1)
