@@ -32,12 +32,15 @@ struct Gold {
     struct E {
         uint32_t l[2];
     };
-    // Lazy dot products (the role U29's column accumulators play): a term is NOT reduced.  With a = a1 2^32 + a0 the
-    // two partial products a0*c and a1*c are < 2^96 each and are summed in two 128-bit accumulators -- plain
-    // add-with-carry chains, 2^32 terms of headroom -- and one reduction per dot product folds them:
-    // sum = lo + 2^32 hi (mod p).  (A reduced multiply-add per term costs ~45 instructions here, this ~14.)
+    // Lazy dot products (the role U29's column accumulators play): a term is NOT reduced.  With a = a1 2^32 + a0 and
+    // c = c1 2^32 + c0 the four 32 x 32 partial products go to three COLUMNS (a0 c0 | a0 c1 + a1 c0 | a1 c1), each a
+    // 64-bit sum with a 32-bit carry count: one v_mad_u64_u32 (carry out) + one v_addc per product, 8 instructions
+    // per term, 2^32 terms of headroom, and ONE reduction per dot product folds the columns:
+    // sum = C0 + 2^32 C1 + 2^64 C2 (mod p).  (128-bit accumulators through the compiler cost ~20 issue slots per
+    // term -- carry juggling through SGPR pairs with hazard nops -- and a reduced multiply-add per term ~45.)
     struct Acc {
-        unsigned __int128 lo, hi;
+        uint64_t c0, c1, c2;
+        uint32_t h0, h1, h2;
     };
     static HB_DEV uint64_t u(const E& a) { return ((uint64_t)a.l[1] << 32) | a.l[0]; }
     static HB_DEV E e(uint64_t v) {
@@ -83,14 +86,32 @@ struct Gold {
     static HB_DEV E mulc_u(const E& a, const uint32_t* __restrict__ c) { return mont(a, c); }
     static HB_DEV E mont(const E& a, const E& b) { return e(mulm(u(a), u(b))); }
 
-    static HB_DEV void acc_zero(Acc& A) { A.lo = 0, A.hi = 0; }
-    static HB_DEV void acc_mac_u64(Acc& A, uint64_t a, uint64_t c) {
-        A.lo += (unsigned __int128)(uint32_t)a * c;
-        A.hi += (unsigned __int128)(uint32_t)(a >> 32) * c;
+    static HB_DEV void acc_zero(Acc& A) { A.c0 = A.c1 = A.c2 = 0, A.h0 = A.h1 = A.h2 = 0; }
+    // One term = ONE asm statement (the compiler pads hazard nops between separate asm statements that touch vcc):
+    // four (v_mad_u64_u32 with carry out, v_addc into the column's carry count) pairs.
+#define HB_GOLD_MAC(CK)                                                                                              \
+    asm("v_mad_u64_u32 %0, vcc, %6, %8, %0\n\tv_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\t"                            \
+        "v_mad_u64_u32 %1, vcc, %6, %9, %1\n\tv_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"                            \
+        "v_mad_u64_u32 %1, vcc, %7, %8, %1\n\tv_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"                            \
+        "v_mad_u64_u32 %2, vcc, %7, %9, %2\n\tv_addc_co_u32_e32 %5, vcc, 0, %5, vcc"                                 \
+        : "+v"(A.c0), "+v"(A.c1), "+v"(A.c2), "+v"(A.h0), "+v"(A.h1), "+v"(A.h2)                                     \
+        : "v"(a.l[0]), "v"(a.l[1]), CK(c0), CK(c1)                                                                   \
+        : "vcc")
+    static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) {
+        const uint32_t c0 = c[0], c1 = c[1];
+        HB_GOLD_MAC("v");
     }
-    static HB_DEV void acc_mac(Acc& A, const E& a, const uint32_t* __restrict__ c) { acc_mac_u64(A, u(a), ((uint64_t)c[1] << 32) | c[0]); }
-    static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[2]) { acc_mac_u64(A, u(a), ((uint64_t)c[1] << 32) | c[0]); }
-    static HB_DEV void acc_add_hi(Acc& A, const E& x) { A.lo += u(x); }
+    // constants from SGPRs: wave-uniform by the caller's promise (they come through the scalar cache)
+    static HB_DEV void acc_mac_pinned(Acc& A, const E& a, const uint32_t (&c)[2]) {
+        const uint32_t c0 = c[0], c1 = c[1];
+        HB_GOLD_MAC("s");
+    }
+#undef HB_GOLD_MAC
+    static HB_DEV void acc_add_hi(Acc& A, const E& x) {
+        const uint64_t v = u(x), s = A.c0 + v;
+        A.h0 += s < v;
+        A.c0 = s;
+    }
     static HB_DEV void acc_fold(Acc&) {}
     template <int M_TOTAL>
     static HB_DEV void acc_fold_needed(Acc&) {}
@@ -105,7 +126,14 @@ struct Gold {
         if (r < t0) r += EPS;
         return r >= P ? r - P : r;
     }
-    static HB_DEV E acc_reduce(Acc& A) { return e(addm(reduce128(A.lo), mulm(reduce128(A.hi), 1ull << 32))); }
+    // a 96-bit column col + 2^64 cnt -> canonical residue
+    static HB_DEV uint64_t reduce96(uint64_t col, uint32_t cnt) { return reduce128(((unsigned __int128)cnt << 64) | col); }
+    static HB_DEV E acc_reduce(Acc& A) {
+        const uint64_t r0 = reduce96(A.c0, A.h0), r1 = reduce96(A.c1, A.h1), r2 = reduce96(A.c2, A.h2);
+        // r0 + 2^32 r1 + 2^64 r2 with 2^64 = EPS (mod p): two modular products by constants, one fused 128-bit fold
+        const unsigned __int128 t = (unsigned __int128)r0 + ((unsigned __int128)r1 << 32) + (unsigned __int128)r2 * EPS;  // < 2^98
+        return e(reduce128(t));
+    }
 
     static HB_DEV E cond_sub_r(const E& x) { return x; }
     static HB_DEV E canon_loose(const E& x) { return x; }
