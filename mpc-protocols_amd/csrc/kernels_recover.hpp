@@ -40,7 +40,8 @@ struct RecoverArgs {
 struct RowsArg {
     uint8_t r[256];
 };
-__global__ inline void k_store_rows(RowsArg a, int* __restrict__ dst, int S, uint32_t* __restrict__ counters,
+template <int = 0>
+__global__ void k_store_rows(RowsArg a, int* __restrict__ dst, int S, uint32_t* __restrict__ counters,
                                     uint32_t* __restrict__ summary) {
     const int i = threadIdx.x;
     if (i < S) dst[i] = a.r[i];

@@ -43,7 +43,7 @@ void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, hipStream_t s
     }
 }
 void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s) {
-    hipLaunchKernelGGL(k_store_rows, dim3(1), dim3(256), 0, s, rows, dst, S, counters, summary);
+    hipLaunchKernelGGL((k_store_rows<0>), dim3(1), dim3(256), 0, s, rows, dst, S, counters, summary);
 }
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s) {
     const unsigned grid = (unsigned)((S + 255) / 256);
