@@ -62,7 +62,7 @@ def cpu_baseline(n, d, sample):
         assert rc == 0
         reps += 1
         dt = time.perf_counter() - t0
-    return {"value": n * sample * reps / dt, "unit": "share-evals/s", "cores": 1, "kind": "port",
+    return {"value": n * sample * reps / dt, "unit": "shares/s", "cores": 1, "kind": "port",
             "sample": f"compute_shares n={n} d={d}: {reps} passes over {sample} secrets, single thread, "
                       f"{os.path.basename(cref.build())}", "seconds": round(dt, 2)}
 
@@ -80,7 +80,7 @@ def cpu_baseline_threads(n, d, sample):
         rcs = list(ex.map(lambda x: cref.compute_shares(x, n, d)[0], xs))
         dt = time.perf_counter() - t0
     assert not any(rcs)
-    return {"value": n * per * cores / dt, "unit": "share-evals/s", "cores": cores, "kind": "port",
+    return {"value": n * per * cores / dt, "unit": "shares/s", "cores": cores, "kind": "port",
             "sample": f"compute_shares n={n} d={d} on {per} secrets per thread", "seconds": round(dt, 2)}
 
 
@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--cpu-sample-log2", type=int, default=22)
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--final-gather", action="store_true",
+                    help="N > 1: after the timed region, all-gather the shares of all ranks once (the path's only "
+                         "collective, optional for consumers that read per-device slices) and report its time")
     ap.add_argument("--impl", default="u29", choices=["u29", "sat32"])
     args = ap.parse_args()
 
@@ -170,8 +173,10 @@ def main():
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
     out = {
-        "metric": "share-evals/sec (RobustShare::compute_shares, 256-bit Fr)",
-        "value": value, "unit": "share-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        # BASELINE.json's metric, verbatim.  `value` is its compute_shares half on BASELINE configs[1] (one share = one
+        # evaluation of one secret's polynomial at one party's point); the batch_recon half is `recons_per_s` (N = 1)
+        "metric": "shares/sec (compute_shares) + recons/sec (batch_recon), 256-bit Fr, 1/2/4/8 GPU",
+        "value": value, "unit": "shares/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": secs / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"compute_shares n={n} t={t} batch=2^{args.log2_batch} secrets per GPU (BASELINE configs[1])",
@@ -204,6 +209,20 @@ def main():
             out["roofline"]["peak_measured_copy_GBps"] = out["extra"]["device_copy_GBps"]
             out["roofline"]["same_traffic_no_arithmetic_GBps"] = 4900.0
             out["roofline"]["frac_of_same_traffic_floor"] = achieved / 4900.0
+    if world > 1 and args.final_gather:
+        # SURVEY 8(e) / north_star: "RCCL over xGMI used only for the final gather" -- outside the timed region
+        from mpc_protocols_amd import sharding
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        g0.record()
+        full = sharding.gather_party_major(shares, B * world)
+        g1.record()
+        torch.cuda.synchronize()
+        lo_b = rank * B
+        assert torch.equal(full[:, lo_b:lo_b + B], shares)
+        out["final_gather"] = {"ms": g0.elapsed_time(g1), "bytes_per_rank": n * B * 32,
+                               "GBps_per_rank_received": n * B * 32 * (world - 1) / g0.elapsed_time(g1) / 1e6}
+        del full
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -7,4 +7,5 @@ The directory name carries a hyphen (it is the reference's repository name), so 
 `__graft_entry__.load_package()` which registers it as the module `mpc_protocols_amd`.
 """
 from . import hbmpc, pipelines  # noqa: F401
+# `sharding` (torch.distributed helpers of the multi-GPU layout) is imported on demand: it needs torch
 from .hbmpc import Engine, HbmpcError, build, lib  # noqa: F401

@@ -63,3 +63,38 @@ def test_world_size_2_gloo():
     assert res[0][2] == res[1][2]                        # both ranks report the max-over-ranks time
     assert res[0][2] >= 5 * 0.004 * 0.9                  # ... which is the slow rank's
     assert res[0][3] == 1000                             # shards cover the batch exactly once
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from __graft_entry__ import load_package
+    from oracle import cref  # stands in for the device compute in this CPU test
+    load_package()
+    from mpc_protocols_amd import sharding
+    n, d, total = 7, 2, 101                                  # 101 over 2 ranks: ragged shards (51 + 50)
+    coeffs = cref.fill_random(77, total * (d + 1)).reshape(total, d + 1, 4)
+    lo, hi = sharding.shard_range(total, rank, world)
+    rc, mine = cref.compute_shares(coeffs[lo:hi], n, d)      # this rank's slice of the batch: [n][hi - lo]
+    assert rc == 0
+    got = sharding.gather_party_major(torch.from_numpy(mine.view(np.int64)), total)
+    rc, want = cref.compute_shares(coeffs, n, d)
+    q.put((rank, bool(np.array_equal(got.numpy().view(np.uint64), want)), tuple(got.shape)))
+    dist.destroy_process_group()
+
+
+def test_final_gather_world_size_2_gloo():
+    """the path's only collective -- every rank ends up with party-major [n][total] rows equal to the
+    single-device result, ragged shards included."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 17) % 1000
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, (7, 101, 4)), (1, True, (7, 101, 4))]
