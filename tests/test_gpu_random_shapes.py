@@ -87,7 +87,8 @@ def test_random_encode_decode(engines, field, seed):
     kmax = t if n <= 40 else min(t, 2)
     for g in range(G):
         mode = rng.randrange(4)
-        k = 0 if mode == 0 else (rng.randint(1, kmax) if (mode < 3 or n > 40) else rng.randint(t + 1, min(S_cnt, 2 * t + 2)))
+        hi = min(S_cnt, 2 * t + 2)
+        k = 0 if mode == 0 else (rng.randint(1, kmax) if (mode < 3 or n > 40) else (rng.randint(t + 1, hi) if hi > t else hi))
         for i in rng.sample(ids, min(k, S_cnt)):
             ev[i][g] = (ev[i][g] + rng.randrange(1, P)) % P
     eng.set_small_batch_chunks(0)                             # the lane-per-chunk kernels of the large batches ...
