@@ -372,6 +372,24 @@ def goldilocks_measurements(torch, dev, stream, ev_time):
             by = (d + t + 1 + d + 1) * 8 * G
             res["gl_cfg3_decode"] = {"recons_per_s": G / ms * 1e3, "ms": ms, "GBps_algorithmic": by / ms / 1e6,
                                      "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS}
+        del x, y
+    # config 4's shape in the small field (TripleGenNode over GoldilocksField, PreprocNodesSmallField): all 16 parties
+    n, t = 16, 5
+    N = ((1 << 22) // (2 * t + 1)) * (2 * t + 1)
+    tg = load_package().pipelines.TripleGen(eng, n, t, N, stream)
+
+    def share(secrets, d, out_ptr):
+        co = rand(N, d + 1)
+        co[:, 0] = secrets
+        assert eng.dev_compute_shares(co.data_ptr(), N, n, d, out_ptr, stream) == 0, eng.last_error()
+        torch.cuda.synchronize()
+
+    a, b, r = rand(N), rand(N), rand(N)
+    share(a, t, tg.a), share(b, t, tg.b), share(r, t, tg.rt), share(r, 2 * t, tg.r2t)
+    tg.run(check=True)
+    ms = ev_time(lambda: tg.run(check=False), reps=5, warm=1)
+    res["gl_cfg4_triple_gen_16_parties"] = {"triples_per_s": N / ms * 1e3, "ms": ms, "triples": N}
+    tg.close()
     eng.close()
     return res
 

@@ -73,12 +73,15 @@ class _Capturable:
 
 
 class TripleGen(_Capturable):
-    """n parties, threshold t, N triples (N a multiple of 2t+1).  Buffers are [party][N] canonical."""
+    """n parties, threshold t, N triples (N a multiple of 2t+1).  Buffers are [party][N] canonical.
+    Works in either field: the reference runs TripleGenNode over Fr and, in PreprocNodesSmallField
+    (honeybadger/mod.rs:316-324), over GoldilocksField -- the element size follows the engine's field."""
 
     def __init__(self, eng, n, t, N, stream=0):
         assert N % (2 * t + 1) == 0
         self.eng, self.n, self.t, self.N, self.stream = eng, n, t, N, stream
         self.m = 2 * t + 1
+        U = 32 if eng.field == "fr" else 8  # bytes per element
         self.G = N // self.m
         G = self.G
         self.arena = DeviceArena(eng, (5 * n * N + n * n * G + n * G + N) * U + (n + 2) * G + (1 << 14))
@@ -119,7 +122,7 @@ class TripleGen(_Capturable):
         _check(e.dev_elem_parties("triple_finalize", [self.rt, self.opened, self.c], N, n, stream=s), e, "triple_finalize")
 
     def download_c(self):
-        out = np.zeros((self.n, self.N, 4), dtype=np.uint64)
+        out = self.eng._new((self.n, self.N))
         self.eng.d2h(out, self.c, self.stream)
         self.eng.sync(self.stream)
         return out

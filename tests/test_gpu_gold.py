@@ -296,3 +296,30 @@ def test_full_size_roundtrip_and_linearity(eng):
 def test_golden_vectors(eng):
     from tests import golden_util as GU
     assert GU.run_all(eng, field="goldilocks") > 90
+
+
+@pytest.mark.parametrize("n,t,groups", [(4, 1, 9), (7, 2, 30), (16, 5, 120)])
+def test_small_field_triple_gen_pipeline(eng, n, t, groups):
+    """TripleGenNode over GoldilocksField (PreprocNodesSmallField, honeybadger/mod.rs:316-324) as a device-resident
+    replay of all n parties: local a_i b_i - r2t_i, Vandermonde encode, the n EvalBatch decodes, the RevealBatch
+    decode, rt_i + opened.  [c]_t must open to a b and every share must equal the reference algebra."""
+    pkg = load_package()
+    N = groups * (2 * t + 1)
+    rng = random.Random(1000 * n + t)
+    a, b, r = ([rng.randrange(P) for _ in range(N)] for _ in range(3))
+
+    def share_all(secrets, d):  # [n][N] degree-d sharings through the oracle
+        rows = [[s.v for s in S.compute_shares([x] + [rng.randrange(P) for _ in range(d)], n, d)] for x in secrets]
+        return np.array(rows, dtype=np.uint64).T.copy()
+
+    sa, sb, srt, sr2t = share_all(a, t), share_all(b, t), share_all(r, t), share_all(r, 2 * t)
+    tg = pkg.pipelines.TripleGen(eng, n, t, N)
+    tg.upload(sa, sb, sr2t, srt)
+    tg.run()
+    c = tg.download_c()
+    tg.close()
+    opened = [(x * y - z) % P for x, y, z in zip(a, b, r)]
+    for p in range(n):
+        assert [int(v) for v in c[p]] == [(int(srt[p, i]) + opened[i]) % P for i in range(N)]
+    rc, p0, st = eng.batch_recover_p0(list(range(n)), c, n, t, t)
+    assert rc == 0 and [int(v) for v in p0] == [x * y % P for x, y in zip(a, b)]
