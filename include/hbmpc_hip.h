@@ -146,6 +146,9 @@ ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs_dev, 
  * ark_std/rand generator, robust_interpolate.rs:66-67): a deployment that needs bit-equality with a given Rust rng
  * keeps drawing on the host and calls hbmpc_compute_shares.  first_index lets a dealer split one seed over several
  * calls / GPUs without reusing stream positions (rank r of W deals indices [r B, (r+1) B)).
+ * secrets (host or device) may be NULL: the secret of every polynomial is then drawn as well, as coefficient k = 0
+ * of the same stream -- the dealer loop of RanSha (share_gen/share_gen.rs:249-256: `F::rand(rng)` followed by
+ * compute_shares) without a host rng; the secrets are column 0 of the workspace.
  * coeffs_ws_dev[B][d+1]: caller-provided workspace that receives the full coefficient rows (row b = secret b, then
  * the d draws) -- the dealer usually needs them again (e.g. to open or to verify).
  * Errors: as hbmpc_compute_shares. */

@@ -609,7 +609,7 @@ static ShareErrorCode fill_coeffs_dev(hbmpc_ctx* ctx, const uint8_t seed[32], co
     if (!seed) return fail(ctx, InvalidInput, "null seed");
     if (d > (1u << 20)) return fail(ctx, InvalidInput, "degree beyond the supported range");
     if (B == 0) return ShareSuccess;
-    if (!secrets || !coeffs_out) return fail(ctx, InvalidInput, "null buffer");
+    if (!coeffs_out) return fail(ctx, InvalidInput, "null buffer");  // secrets may be null: they are drawn too
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint32_t k[8];
     memcpy(k, seed, 32);  // little-endian words
@@ -631,12 +631,12 @@ static ShareErrorCode compute_shares_seeded_host(hbmpc_ctx* ctx, const uint8_t s
     if (!ctx) return InvalidInput;
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
     if (B == 0) return ShareSuccess;
-    if (!secrets || !shares_out || !seed) return fail(ctx, InvalidInput, "null buffer");
+    if (!shares_out || !seed) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t eb = ebytes(ctx);
     Stage st(ctx, B * (1 + d + 1 + n) * eb, 3);  // only the SECRETS cross the bus on the way in: 1/(d+1) of what hbmpc_compute_shares uploads
-    void *ds, *dc, *dy;
-    HIP_TRY(ctx, st.in(secrets, B * eb, &ds));
+    void *ds = nullptr, *dc, *dy;
+    if (secrets) HIP_TRY(ctx, st.in(secrets, B * eb, &ds));
     HIP_TRY(ctx, st.alloc(B * (d + 1) * eb, &dc));
     HIP_TRY(ctx, st.alloc(B * n * eb, &dy));
     ShareErrorCode rc = compute_shares_seeded_dev(ctx, seed, ds, B, first_index, n, d, dc, dy, nullptr);

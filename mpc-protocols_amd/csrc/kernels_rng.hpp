@@ -40,7 +40,8 @@ __device__ __forceinline__ void chacha20_block(const SeedArg& key, uint64_t coun
 }
 #undef HB_QR
 
-// coeffs[b][0] = secrets[b]; coeffs[b][k] = seeded coefficient (first_index + b, k), k = 1..d.  One lane per element.
+// coeffs[b][0] = secrets[b] (or seeded coefficient (first_index + b, 0) when secrets is null);
+// coeffs[b][k] = seeded coefficient (first_index + b, k), k = 1..d.  One lane per element.
 // EW = u32 words per element: 8 (bls12-381 Fr) or 2 (Goldilocks).
 template <int EW>
 __global__ __launch_bounds__(256) void k_fill_coeffs(SeedArg seed, const uint32_t* __restrict__ secrets, size_t B,
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_fill_coeffs(SeedArg seed, const uint32_
     const size_t b = e / (size_t)dp1;
     const uint32_t k = (uint32_t)(e - b * (size_t)dp1);
     uint32_t* dst = coeffs + e * EW;
-    if (k == 0) {
+    if (k == 0 && secrets) {  // secrets == nullptr: the secret is drawn too (stream position k = 0): a RanSha dealer
 #pragma unroll
         for (int w = 0; w < EW; ++w) dst[w] = secrets[b * EW + w];
         return;

@@ -131,12 +131,16 @@ class Engine:
         return rc, out
 
     def compute_shares_seeded(self, seed, secrets, n, d, first_index=0):
-        """seed: 32 bytes ("hbmpc-chacha20-v1", include/hbmpc_hip.h); secrets: [B] elements"""
-        secrets = np.ascontiguousarray(secrets)
-        B = secrets.shape[0]
+        """seed: 32 bytes ("hbmpc-chacha20-v1", include/hbmpc_hip.h); secrets: [B] elements, or an int B: the
+        secrets are drawn too"""
+        if isinstance(secrets, int):
+            B, sp = secrets, C.c_void_p(0)
+        else:
+            secrets = np.ascontiguousarray(secrets)
+            B, sp = secrets.shape[0], _p(secrets)
         out = self._new((n, B))
         seed = (C.c_uint8 * 32).from_buffer_copy(bytes(seed))
-        rc = self._f("compute_shares_seeded")(self.ctx, seed, _p(secrets), C.c_size_t(B), C.c_uint64(first_index),
+        rc = self._f("compute_shares_seeded")(self.ctx, seed, sp, C.c_size_t(B), C.c_uint64(first_index),
                                               C.c_size_t(n), C.c_size_t(d), _p(out))
         return rc, out
 

@@ -636,5 +636,7 @@ def seeded_coefficient(seed_words, b: int, k: int) -> int:
         attempt += 1
 
 
-def seeded_polynomial(seed_words, b: int, secret: int, degree: int):
-    return [secret % R_MOD] + [seeded_coefficient(seed_words, b, k) for k in range(1, degree + 1)]
+def seeded_polynomial(seed_words, b: int, secret, degree: int):
+    """secret None: coefficient 0 is drawn from the stream too (position k = 0)"""
+    c0 = seeded_coefficient(seed_words, b, 0) if secret is None else secret % R_MOD
+    return [c0] + [seeded_coefficient(seed_words, b, k) for k in range(1, degree + 1)]

@@ -121,3 +121,27 @@ def test_errors(env):
     assert rc == 4  # InvalidInput: n <= d
     rc, sh = eng.compute_shares_seeded(bytes(32), x[:0], 4, 1)
     assert rc == 0 and sh.shape[1] == 0
+
+
+def test_secrets_drawn_too(env):
+    """secrets = NULL: coefficient 0 comes from the stream as well (RanSha's dealer: a random secret per sharing)"""
+    eng, field = env
+    sp, mod = FIELDS[field]
+    n, d, B, first = 10, 3, 77, 5
+    seed = bytes(range(100, 132))
+    rc, sh = eng.compute_shares_seeded(seed, B, n, d, first_index=first)
+    assert rc == 0
+    got = to_ints(field, sh)
+    for b in range(B):
+        poly = sp.seeded_polynomial(words(seed), first + b, None, d)
+        assert poly[0] == sp.seeded_coefficient(words(seed), first + b, 0)
+        assert [got[j * B + b] for j in range(n)] == [s.v for s in sp.compute_shares(poly, n, d)]
+    ew = 4 if field == "fr" else 1
+    dev = torch.device("cuda:0")
+    co = torch.zeros(B * (d + 1) * ew, dtype=torch.int64, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        assert eng.dev_fill_coeffs(seed, 0, B, first, d, co.data_ptr(), stream=st.cuda_stream) == 0
+    st.synchronize()
+    rows = to_ints(field, co.cpu().numpy().view(np.uint64))
+    assert rows[: d + 1] == sp.seeded_polynomial(words(seed), first, None, d)

@@ -24,6 +24,7 @@ def test_seeded_coefficient_properties():
         assert sp.seeded_coefficient(seed, 3, 2) != sp.seeded_coefficient([9] + seed[1:], 3, 2)
         poly = sp.seeded_polynomial(seed, 7, mod + 5, 4)
         assert poly[0] == 5 and poly[1:] == [sp.seeded_coefficient(seed, 7, k) for k in range(1, 5)]
+        assert sp.seeded_polynomial(seed, 7, None, 4) == [sp.seeded_coefficient(seed, 7, k) for k in range(5)]
 
 
 def test_goldilocks_rejection_is_exercised():
