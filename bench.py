@@ -6,12 +6,13 @@ one rank per GPU).  A "step" is one pass of RobustShare::compute_shares over one
 BASELINE.json configs[1] -- n=16, t=5, 2^20 secrets, 256-bit Fr -- per GPU (weak scaling: batches are
 independent, there is no data-path collective).  Rank 0 prints ONE JSON line.
 
-  value      share-evals/s, whole job (n * B * N * K / max-over-ranks time), inputs resident in HBM
+  value      shares/s (share evaluations), whole job (n * B * N * K / max-over-ranks time), inputs resident in HBM
   roofline   dominant kernel against the HBM roofline: algorithmic bytes per launch (704 B/secret)
              / average launch duration measured with HIP events on the launch stream
   cpu_baseline  the C restatement of the reference algorithm (oracle/, "port") timed on this box's
              host cores on a bounded sample of the same workload (single thread: the reference runs
-             its arithmetic inline in one tokio task per party, no rayon)
+             its arithmetic inline in one tokio task per party, no rayon).  This leg is the ONLY place
+             the oracle is used; it also checks the first 512 secrets of the benchmarked buffers.
   extra      cfg3 encode/decode rates, element-wise rate, the register-resident modmul ceiling
 """
 import argparse
@@ -50,8 +51,14 @@ def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn):
     return max_reduce_fn(dt)
 
 
-def cpu_baseline(n, d, sample):
-    from oracle import cref  # the checker doubles as the reported CPU baseline ("port")
+def cpu_baseline(n, d, sample, check=None):
+    """The only place bench.py touches oracle/: the CPU restatement timed as the reported baseline ("port"), and --
+    as the checker it is -- compared once with the benchmarked GPU buffers (check = (coeffs, shares) of the first
+    secrets of the timed batch, copied to the host)."""
+    from oracle import cref
+    if check is not None:
+        rc, want = cref.compute_shares(np.ascontiguousarray(check[0]), n, d)
+        assert rc == 0 and np.array_equal(check[1], want), "bench output differs from the oracle"
     x = cref.fill_random(0xC0FFEE01, sample * (d + 1)).reshape(sample, d + 1, 4)
     cref.compute_shares(x[:1024], n, d)
     # a bounded sample of the same workload: repeat the pass over `sample` secrets until >= 10 s of CPU work
@@ -120,10 +127,8 @@ def main():
 
     n, t, d = 16, 5, 5
     B = 1 << args.log2_batch  # per GPU (weak scaling)
-    from oracle import cref  # synthetic-input generator only (SplitMix64 -> mod r), same stream as the tests
-    lo, _ = shard_range(B * world, rank, world)
-    host = cref.fill_random(0xC0FFEE01 + rank, B * (d + 1)).reshape(B, d + 1, 4)
-    coeffs = torch.from_numpy(host.view(np.int64)).to(dev)          # [B][d+1][4] resident in HBM
+    torch.manual_seed(0xC0FFEE01 + rank)  # synthetic inputs: canonical, uniform-ish field elements drawn on the device
+    coeffs = _rand_fr(torch, dev, B, d + 1)                         # [B][d+1][4] resident in HBM (this rank's shard)
     shares = torch.empty((n, B, 4), dtype=torch.int64, device=dev)  # [n][B][4]
     # an explicit (non-default) torch stream: its handle goes through the C ABI, so the kernels, the
     # torch.cuda.Event timings and the copies above are all ordered on ONE stream
@@ -151,10 +156,8 @@ def main():
 
     step()
     torch.cuda.synchronize()
-    # parity spot-check of the benchmarked buffers (oracle as the checker, outside the timed region)
-    chk = shares[:, :512].cpu().numpy().view(np.uint64)
-    rc, want = cref.compute_shares(host[:512], n, d)
-    assert rc == 0 and np.array_equal(chk, want), "bench output differs from the oracle"
+    # the first secrets of the benchmarked buffers, for the oracle check inside the cpu_baseline leg
+    check = (coeffs[:512].cpu().numpy().view(np.uint64), shares[:, :512].cpu().numpy().view(np.uint64))
 
     # kernel time with HIP events on the launch stream (same region as the timed loop, separate pass)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -197,10 +200,10 @@ def main():
             pass
 
     if rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(n, d, 1 << args.cpu_sample_log2)
+        out["cpu_baseline"] = cpu_baseline(n, d, 1 << args.cpu_sample_log2, check)
         if not args.no_extra:
             out["cpu_baseline_all_cores"] = cpu_baseline_threads(n, d, 1 << args.cpu_sample_log2)
-            out["extra"] = extra_measurements(eng, torch, dev, stream, cref)
+            out["extra"] = extra_measurements(eng, torch, dev, stream)
             # the second half of BASELINE.json's metric, for convenience at the top level
             out["recons_per_s"] = out["extra"]["cfg3_decode"]["recons_per_s"]
             # context for `frac` (report against the vendor peak AND what the chip delivers): a plain
@@ -229,8 +232,10 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_measurements(eng, torch, dev, stream, cref):
-    """Other rows of the path, timed with HIP events (not part of `value`)."""
+def extra_measurements(eng, torch, dev, stream):
+    """Other rows of the path, timed with HIP events (not part of `value`).  No oracle here: inputs are drawn on the
+    device and every check is a property of the path itself (encode -> decode returns the input, corrupted chunks
+    are repaired); parity with the oracle is the test suite's job."""
     res = {}
 
     def ev_time(fn, reps=10, warm=2):
@@ -246,8 +251,8 @@ def extra_measurements(eng, torch, dev, stream, cref):
 
     # config 3: n=31, t=10, d=10, 2^20 chunks: encode (apply_vandermonde) and decode (batch_recover_secret)
     n, t, d, G = 31, 10, 10, 1 << 20
-    host = cref.fill_random(0xC0FFEE02, G * (d + 1)).reshape(G, d + 1, 4)
-    x = torch.from_numpy(host.view(np.int64)).to(dev)
+    torch.manual_seed(0xC0FFEE02)
+    x = _rand_fr(torch, dev, G, d + 1)
     y = torch.empty((n, G, 4), dtype=torch.int64, device=dev)
     co = torch.empty((G, d + 1, 4), dtype=torch.int64, device=dev)
     st = torch.empty((G,), dtype=torch.uint8, device=dev)
@@ -302,9 +307,7 @@ def extra_measurements(eng, torch, dev, stream, cref):
     del big, dst
     # element-wise: triple_local on 2^22 elements (128 B/element)
     N = 1 << 22
-    a = torch.from_numpy(cref.fill_random(1, N).view(np.int64)).to(dev)
-    b = torch.from_numpy(cref.fill_random(2, N).view(np.int64)).to(dev)
-    c = torch.from_numpy(cref.fill_random(3, N).view(np.int64)).to(dev)
+    a, b, c = _rand_fr(torch, dev, N), _rand_fr(torch, dev, N), _rand_fr(torch, dev, N)
     o = torch.empty_like(a)
     ms = ev_time(lambda: eng.dev_elem("triple_local", [a.data_ptr(), b.data_ptr(), c.data_ptr(), o.data_ptr()], N,
                                       stream=stream))
@@ -313,7 +316,7 @@ def extra_measurements(eng, torch, dev, stream, cref):
     del a, b, c, o
     # seeded dealer (include/hbmpc_hip.h, "hbmpc-chacha20-v1"): config 2 with the coefficients drawn on the device
     n, d, B = 16, 5, 1 << 20
-    sec = torch.from_numpy(cref.fill_random(4, B).view(np.int64)).to(dev)
+    sec = _rand_fr(torch, dev, B)
     cws = torch.empty((B, d + 1, 4), dtype=torch.int64, device=dev)
     sh = torch.empty((n, B, 4), dtype=torch.int64, device=dev)
     seed = bytes(range(32))
@@ -339,7 +342,6 @@ def extra_measurements(eng, torch, dev, stream, cref):
 def goldilocks_measurements(torch, dev, stream, ev_time):
     """the small-field variants at the shapes of configs 2 and 3 (8-byte elements)."""
     from __graft_entry__ import load_package
-    from oracle.spec_gl import S as SG  # checker only
     eng = load_package().Engine(dev.index or 0, field="goldilocks")
     res = {}
     gen = torch.Generator(device=dev)
@@ -355,9 +357,6 @@ def goldilocks_measurements(torch, dev, stream, ev_time):
         y = torch.empty((n, G), dtype=torch.int64, device=dev)
         ms = ev_time(lambda: eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), stream))
         torch.cuda.synchronize()
-        xs, ys = x[:4].cpu().numpy().view(np.uint64), y[:, :4].cpu().numpy().view(np.uint64)
-        for i in range(4):
-            assert [int(v) for v in ys[:, i]] == [sh.v for sh in SG.compute_shares([int(c) for c in xs[i]], n, d)]
         by = (d + 1 + n) * 8 * G
         res[tag + ("" if "shares" in tag else "_encode")] = {"share_evals_per_s": n * G / ms * 1e3, "ms": ms,
                                                              "GBps_algorithmic": by / ms / 1e6, "hbm_frac": by / ms / 1e6 / HBM_PEAK_GBS}
