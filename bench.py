@@ -298,6 +298,17 @@ def extra_measurements(eng, torch, dev, stream):
     assert bool((co == x).all()) and int(sm[0]) == G // 100 and int(sm[1]) == 0, sm
     res["cfg3_decode_1pct_corrupted"] = {"recons_per_s": G / ms * 1e3, "ms": ms, "fallback_chunks": int(sm[0]),
                                          "note": "t lowest-id senders corrupted in 1 % of chunks"}
+    # one Byzantine sender (the lowest id: inside the interpolation set) lies in EVERY chunk: the whole batch fails the
+    # optimistic verification; the second-chance candidates resolve it without the OEC/Gao kernel
+    y[:t, bad, 0] ^= 1
+    y[0, :, 0] ^= 1
+    ms = ev_time(lambda: eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, co.data_ptr(), 0, st.data_ptr(),
+                                               summ.data_ptr(), stream), reps=3, warm=1)
+    torch.cuda.synchronize()
+    sm = summ.cpu().numpy().view(np.uint32)
+    assert bool((co == x).all()) and int(sm[0]) == G and int(sm[1]) == 0, sm
+    res["cfg3_decode_byzantine_sender"] = {"recons_per_s": G / ms * 1e3, "ms": ms, "fallback_chunks": int(sm[0]),
+                                           "note": "sender 0 lies in every chunk"}
     del x, y, co, sec
     # achievable HBM rate of a plain device copy (report against the vendor peak AND this)
     big = torch.empty((1 << 27,), dtype=torch.int64, device=dev)  # 1 GiB

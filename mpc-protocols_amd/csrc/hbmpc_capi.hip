@@ -43,6 +43,7 @@ struct hbmpc_ctx {
     size_t evictions = 0;                          // flushes of the table cache so far
     std::vector<void*> pin_free;                   // pinned, device-mapped staging blocks of small host-pointer calls (Stage)
     size_t wide_max_chunks = 8192;                 // batch_recover calls up to this many chunks (evaluations: a quarter of it) use the wave-per-chunk kernels
+    bool second_chance = true;                     // flagged chunks try two cheap interpolation candidates before OEC/Gao
     bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
     std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
@@ -227,6 +228,11 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
 extern "C" ShareErrorCode hbmpc_set_small_batch_chunks(hbmpc_ctx* ctx, size_t max_chunks) {
     if (!ctx) return InvalidInput;
     ctx->wide_max_chunks = max_chunks;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_second_chance(hbmpc_ctx* ctx, int on) {
+    if (!ctx) return InvalidInput;
+    ctx->second_chance = on != 0;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_cache_stats(hbmpc_ctx* ctx, size_t stats_out[4]) {

@@ -247,4 +247,84 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(RecoverArgs a) {
         if (r >= nv) F::store_loose(a.out + (g * (size_t)ow + (r - nv)) * F::EW, dot(r));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second chance for flagged chunks, before the OEC/Gao kernel.  The reference's fallback (oec_decode,
+// robust_interpolate.rs:579-628) returns THE polynomial of degree <= d that agrees with at least d+t+1 of the first
+// needed + r sorted shares for some round r <= min(t, S - needed) -- it is unique across rounds (two such polynomials
+// share >= d+1 points), Gao's decoder finds it whenever it exists (<= r errors, capacity (t + r) / 2), and agreement
+// on a prefix only grows with r.  So a candidate that interpolates ANY d+1 of those shares and disagrees with at
+// most rmax of the first P = needed + rmax IS that polynomial.  Two candidates cost a few dot products each:
+// window A = the lowest d+1 senders (right whenever the liars sit in the verify rows), window B = the next d+1
+// (right whenever they sit in A).  A single Byzantine sender -- the case that otherwise sends EVERY chunk of a
+// batch down a path 20x slower than the optimistic one -- is always caught by one of the two.  What neither
+// resolves goes on to k_gao through a second list.  Lane per flagged chunk; inputs are re-read through the cache.
+struct SecondArgs {
+    const uint32_t* evals;
+    size_t G, row_stride;
+    const int* rows;
+    int m, P, rmax, n_windows, out_width;
+    int win_start[2];
+    const uint32_t* ev[2];       // [(P - m)][m] rows L_i(x_s), s ascending over the positions outside the window
+    const uint32_t* bc[2];       // [m][m]
+    const uint32_t* flagged;     // chunks the optimistic kernel flagged; counters[0] of them
+    uint32_t* flagged2;          // chunks left for k_gao; counters[1] of them
+    uint32_t* counters;
+    uint32_t* out;
+    uint32_t* ncoeffs;
+    uint8_t* status;
+    uint32_t* summary;
+};
+template <class F>
+HB_DEV typename F::E second_dot(const SecondArgs& a, size_t g, int ws, const uint32_t* __restrict__ row) {
+    typename F::Acc acc;
+    F::acc_zero(acc);
+    int pending = 0;
+    for (int i = 0; i < a.m; ++i) {
+        if (pending == F::MAX_DOT_TERMS) {
+            F::acc_fold(acc);
+            pending = 1;
+        }
+        F::acc_mac(acc, F::load(a.evals + ((size_t)a.rows[ws + i] * a.row_stride + g) * F::EW), row + i * F::NL);
+        ++pending;
+    }
+    F::acc_fold(acc);
+    return F::canon_loose(F::acc_reduce(acc));
+}
+template <class F>
+HB_DEV void second_chance_one(const SecondArgs& a, size_t g) {
+    using E = typename F::E;
+    const int M = a.m;
+    for (int w = 0; w < a.n_windows; ++w) {
+        const int ws = a.win_start[w];
+        int mism = 0;
+        for (int e = 0; e < a.P - M && mism <= a.rmax; ++e) {
+            const int s = e < ws ? e : e + M;  // e-th position outside [ws, ws + M)
+            const E p = second_dot<F>(a, g, ws, a.ev[w] + (size_t)e * M * F::NL);
+            const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + g) * F::EW);
+            mism += F::eq_canon(p, ys) ? 0 : 1;
+        }
+        if (mism > a.rmax) continue;
+        // accepted: coefficients, zero padded by construction; DensePolynomial length for the fallback's trimmed row
+        int len = 0;
+        for (int k = 0; k < M; ++k) {
+            if (k >= a.out_width && !a.ncoeffs) break;
+            const E c = second_dot<F>(a, g, ws, a.bc[w] + (size_t)k * M * F::NL);
+            if (!F::is_zero_canon(c)) len = k + 1;
+            if (k < a.out_width) F::store_lt2r(a.out + (g * (size_t)a.out_width + k) * F::EW, c);
+        }
+        if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)len;
+        if (a.status) a.status[g] = 1;
+        atomicAdd(&a.summary[0], 1u);
+        return;
+    }
+    a.flagged2[atomicAdd(&a.counters[1], 1u)] = (uint32_t)g;
+}
+template <class F>
+__global__ __launch_bounds__(256) void k_second_chance(SecondArgs a) {
+    // grid-stride over the flagged list: the launch is sized for a modest list and costs next to nothing when the
+    // list is empty (the normal case)
+    const size_t count = a.counters[0], step = (size_t)gridDim.x * blockDim.x;
+    for (size_t fi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; fi < count; fi += step) second_chance_one<F>(a, a.flagged[fi]);
+}
+
 }  // namespace hbmpc

@@ -199,4 +199,37 @@ inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids,
     return T;
 }
 
+// "Second chance" tables (kernels_recover.hpp, k_second_chance): for a window W of m consecutive sorted senders,
+// the rows L_i^W(x_s) for every other position s of the OEC prefix [0, P), ascending, followed by the coefficient
+// rows of the basis.  Window A = [0, m) is the optimistic path's interpolation set again (its verify rows extended
+// from `needed` to P); window B = [m, 2m) exists when it fits the prefix.
+struct SecondTables {
+    std::vector<uint32_t> words;
+    int n_windows = 0;
+    int win_start[2] = {0, 0};
+    uint32_t ev_off[2] = {0, 0}, bc_off[2] = {0, 0};
+};
+template <class H = HFr>
+inline SecondTables build_second_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t P, int impl) {
+    const size_t m = d + 1;
+    std::vector<H> el = domain_elements<H>(n, n);
+    SecondTables T;
+    for (size_t ws = 0; ws + m <= P && T.n_windows < 2; ws += m) {
+        std::vector<H> xs(m);
+        for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[ws + i]];
+        auto basis = lagrange_basis(xs);
+        const int w = T.n_windows++;
+        T.win_start[w] = (int)ws;
+        T.ev_off[w] = (uint32_t)T.words.size();
+        for (size_t s = 0; s < P; ++s) {
+            if (s >= ws && s < ws + m) continue;
+            for (size_t i = 0; i < m; ++i) put_const(T.words, horner(basis[i], el[sorted_ids[s]]), impl);
+        }
+        T.bc_off[w] = (uint32_t)T.words.size();
+        for (size_t k = 0; k < m; ++k)
+            for (size_t i = 0; i < m; ++i) put_const(T.words, basis[i][k], impl);
+    }
+    return T;
+}
+
 }  // namespace hbmpc

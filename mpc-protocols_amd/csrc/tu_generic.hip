@@ -42,6 +42,11 @@ void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, hipStream_t s
         else hipLaunchKernelGGL((k_batch_recover_wide<Gold, false>), dim3(grid), dim3(256), lds, s, ra);
     }
 }
+void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s) {
+    if (impl == 0) hipLaunchKernelGGL((k_second_chance<U29>), dim3(grid), dim3(256), 0, s, a);
+    else if (impl == 1) hipLaunchKernelGGL((k_second_chance<Sat32>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_second_chance<Gold>), dim3(grid), dim3(256), 0, s, a);
+}
 void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s) {
     hipLaunchKernelGGL((k_store_rows<0>), dim3(1), dim3(256), 0, s, rows, dst, S, counters, summary);
 }

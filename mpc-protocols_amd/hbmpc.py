@@ -113,6 +113,9 @@ class Engine:
     def set_small_batch_chunks(self, max_chunks: int):
         assert self.L.hbmpc_set_small_batch_chunks(self.ctx, C.c_size_t(max_chunks)) == 0
 
+    def set_second_chance(self, on: bool):
+        assert self.L.hbmpc_set_second_chance(self.ctx, C.c_int(1 if on else 0)) == 0
+
     def cache_stats(self):
         out = (C.c_size_t * 4)()
         assert self.L.hbmpc_cache_stats(self.ctx, out) == 0

@@ -29,9 +29,11 @@ def eng(request, _eng):
     Horner / re-reading kernels (what shapes outside the templates fall back to)"""
     _eng.set_force_generic(request.param == "generic")
     _eng.set_small_batch_chunks(0 if request.param == "lane" else 8192)  # lane: the large-batch kernels at every size
+    _eng.set_second_chance(request.param == "fast")  # the other modes: every flagged chunk goes to the OEC/Gao kernel
     yield _eng
     _eng.set_force_generic(False)
     _eng.set_small_batch_chunks(8192)
+    _eng.set_second_chance(True)
 
 
 def rnd(seed, *shape):

@@ -91,9 +91,11 @@ def test_random_encode_decode(engines, field, seed):
         k = 0 if mode == 0 else (rng.randint(1, kmax) if (mode < 3 or n > 40) else (rng.randint(t + 1, hi) if hi > t else hi))
         for i in rng.sample(ids, min(k, S_cnt)):
             ev[i][g] = (ev[i][g] + rng.randrange(1, P)) % P
-    eng.set_small_batch_chunks(0)                             # the lane-per-chunk kernels of the large batches ...
+    eng.set_small_batch_chunks(0)                             # the lane-per-chunk kernels of the large batches and
+    eng.set_second_chance(False)                              # OEC/Gao for every flagged chunk ...
     lane = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
-    eng.set_small_batch_chunks(8192)                          # ... and the default wave-per-chunk kernel: same bytes
+    eng.set_small_batch_chunks(8192)                          # ... and the defaults (wave-per-chunk kernel, second-
+    eng.set_second_chance(True)                               # chance candidates before OEC/Gao): same bytes
     rc, co, nco, st = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
     assert lane[0] == rc and all(np.array_equal(u, v) for u, v in zip(lane[1:], (co, nco, st)))
     if S_cnt < d + t + 1:                                     # robust_interpolate.rs:333-341: "Not enough evaluations"

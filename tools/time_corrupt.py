@@ -16,7 +16,9 @@ st = torch.empty((G,), dtype=torch.uint8, device=dev); summ = torch.zeros((4,), 
 eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), s)
 bad = torch.randperm(G, device=dev)[: int(G * frac)]
 nbad = int(sys.argv[2]) if len(sys.argv) > 2 else t
-y[:nbad, bad, 0] ^= 1
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # id of the first corrupted sender
+if len(sys.argv) > 4: eng.set_second_chance(sys.argv[4] != "gao")
+y[first:first + nbad, bad, 0] ^= 1
 ids = list(range(n))
 for _ in range(2): eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, co.data_ptr(), 0, st.data_ptr(), summ.data_ptr(), s)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -24,4 +26,4 @@ e0.record()
 for _ in range(3): eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, co.data_ptr(), 0, st.data_ptr(), summ.data_ptr(), s)
 e1.record(); torch.cuda.synchronize()
 ok = bool((co == x).all())
-print(f"grid={os.environ.get('HBMPC_GAO_GRID','2048')} frac={frac} corrupted_senders={nbad}: {e0.elapsed_time(e1)/3:.2f} ms, fallback={summ.tolist()[:2]}, correct={ok}")
+print(f"frac={frac} corrupted_senders={nbad} from id {first} ({'OEC/Gao only' if len(sys.argv) > 4 and sys.argv[4] == 'gao' else 'second chance first'}): {e0.elapsed_time(e1)/3:.2f} ms, fallback={summ.tolist()[:2]}, correct={ok}")
