@@ -319,11 +319,50 @@ HB_DEV void second_chance_one(const SecondArgs& a, size_t g) {
     }
     a.flagged2[atomicAdd(&a.counters[1], 1u)] = (uint32_t)g;
 }
+// The same decision with a whole wave per flagged chunk (lane = table row): used when the flagged list is short
+// enough to give every chunk a wave -- one lying share in a one-polynomial recover_secret then costs two dot
+// products of latency per candidate instead of a serial walk over (P - m) + m of them.
+template <class F>
+HB_DEV void second_chance_wave(const SecondArgs& a, size_t g) {
+    using E = typename F::E;
+    const int M = a.m, lane = threadIdx.x & 63;
+    for (int w = 0; w < a.n_windows; ++w) {
+        const int ws = a.win_start[w];
+        bool bad = false;
+        if (lane < a.P - M) {
+            const int s = lane < ws ? lane : lane + M;
+            const E p = second_dot<F>(a, g, ws, a.ev[w] + (size_t)lane * M * F::NL);
+            bad = !F::eq_canon(p, F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + g) * F::EW));
+        }
+        if (__popcll(__ballot(bad)) > a.rmax) continue;
+        bool nonzero = false;
+        if (lane < M && (lane < a.out_width || a.ncoeffs)) {
+            const E c = second_dot<F>(a, g, ws, a.bc[w] + (size_t)lane * M * F::NL);
+            nonzero = !F::is_zero_canon(c);
+            if (lane < a.out_width) F::store_lt2r(a.out + (g * (size_t)a.out_width + lane) * F::EW, c);
+        }
+        const unsigned long long nz = __ballot(nonzero);
+        if (lane == 0) {
+            if (a.ncoeffs) a.ncoeffs[g] = nz ? 64u - (uint32_t)__clzll((long long)nz) : 0u;
+            if (a.status) a.status[g] = 1;
+            atomicAdd(&a.summary[0], 1u);
+        }
+        return;
+    }
+    if (lane == 0) a.flagged2[atomicAdd(&a.counters[1], 1u)] = (uint32_t)g;
+}
 template <class F>
 __global__ __launch_bounds__(256) void k_second_chance(SecondArgs a) {
     // grid-stride over the flagged list: the launch is sized for a modest list and costs next to nothing when the
     // list is empty (the normal case)
-    const size_t count = a.counters[0], step = (size_t)gridDim.x * blockDim.x;
+    const size_t count = a.counters[0];
+    const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+    if (count <= nwaves && a.P - a.m <= 64 && a.m <= 64) {
+        for (size_t fi = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); fi < count; fi += nwaves)
+            second_chance_wave<F>(a, a.flagged[fi]);
+        return;
+    }
+    const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t fi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; fi < count; fi += step) second_chance_one<F>(a, a.flagged[fi]);
 }
 

@@ -24,7 +24,7 @@ for zc, n, t in ((True, 16, 5), (False, 16, 5), (True, 31, 10), (False, 31, 10))
           f" recover_secret {lat(lambda: eng.recover_secret(ids, degs, vals, n, t)):.1f} us;"
           f" batch_recover G=1 {lat(lambda: eng.batch_recover(ids, y, n, d, t)):.1f} us", flush=True)
     bad = vals.copy(); bad[0, 0] ^= np.uint64(1)
-    print(f"   recover_secret with one lie (OEC/Gao) {lat(lambda: eng.recover_secret(ids, degs, bad, n, t), 500):.1f} us", flush=True)
+    print(f"   recover_secret with one lie (fallback) {lat(lambda: eng.recover_secret(ids, degs, bad, n, t), 500):.1f} us", flush=True)
     for G in (64, 1024):
         xb = cref.fill_random(5, G * (d + 1)).reshape(G, d + 1, 4)
         rc, yb = eng.compute_shares(xb, n, d)
