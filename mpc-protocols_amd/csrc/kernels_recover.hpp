@@ -253,9 +253,10 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(RecoverArgs a) {
 // needed + r sorted shares for some round r <= min(t, S - needed) -- it is unique across rounds (two such polynomials
 // share >= d+1 points), Gao's decoder finds it whenever it exists (<= r errors, capacity (t + r) / 2), and agreement
 // on a prefix only grows with r.  So a candidate that interpolates ANY d+1 of those shares and disagrees with at
-// most rmax of the first P = needed + rmax IS that polynomial.  Two candidates cost a few dot products each:
+// most rmax of the first P = needed + rmax IS that polynomial.  Up to four candidates cost a few dot products each:
 // window A = the lowest d+1 senders (right whenever the liars sit in the verify rows), window B = the next d+1
-// (right whenever they sit in A).  A single Byzantine sender -- the case that otherwise sends EVERY chunk of a
+// (right whenever they sit in A), the last d+1 of the prefix and one straddling A and B (tables.hpp,
+// second_windows).  A single Byzantine sender -- the case that otherwise sends EVERY chunk of a
 // batch down a path 20x slower than the optimistic one -- is always caught by one of the two.  What neither
 // resolves goes on to k_gao through a second list.  Lane per flagged chunk; inputs are re-read through the cache.
 struct SecondArgs {
@@ -263,9 +264,9 @@ struct SecondArgs {
     size_t G, row_stride;
     const int* rows;
     int m, P, rmax, n_windows, out_width;
-    int win_start[2];
-    const uint32_t* ev[2];       // [(P - m)][m] rows L_i(x_s), s ascending over the positions outside the window
-    const uint32_t* bc[2];       // [m][m]
+    int win_start[4];
+    const uint32_t* ev[4];       // [(P - m)][m] rows L_i(x_s), s ascending over the positions outside the window
+    const uint32_t* bc[4];       // [m][m]
     const uint32_t* flagged;     // chunks the optimistic kernel flagged; counters[0] of them
     uint32_t* flagged2;          // chunks left for k_gao; counters[1] of them
     uint32_t* counters;

@@ -202,24 +202,56 @@ inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids,
 // "Second chance" tables (kernels_recover.hpp, k_second_chance): for a window W of m consecutive sorted senders,
 // the rows L_i^W(x_s) for every other position s of the OEC prefix [0, P), ascending, followed by the coefficient
 // rows of the basis.  Window A = [0, m) is the optimistic path's interpolation set again (its verify rows extended
-// from `needed` to P); window B = [m, 2m) exists when it fits the prefix.
+// from `needed` to P); the others exist when they fit the prefix.
+constexpr int SECOND_MAX_WINDOWS = 4;
+// candidate windows of m consecutive positions inside the prefix [0, P): the lowest m, the next m, the last m and one
+// straddling the first two -- any window free of liars yields the answer, so more (overlapping) windows only widen the
+// set of liar patterns that never reach OEC/Gao
+inline std::vector<int> second_windows(size_t m, size_t P) {
+    std::vector<int> ws;
+    auto add = [&](size_t o) {
+        if (o + m > P) return;
+        for (int x : ws)
+            if ((size_t)x == o) return;
+        if ((int)ws.size() < SECOND_MAX_WINDOWS) ws.push_back((int)o);
+    };
+    add(0);
+    add(m);
+    add(P >= m ? P - m : 0);
+    add(m / 2 + (m & 1));
+    return ws;
+}
 struct SecondTables {
     std::vector<uint32_t> words;
     int n_windows = 0;
-    int win_start[2] = {0, 0};
-    uint32_t ev_off[2] = {0, 0}, bc_off[2] = {0, 0};
+    int win_start[SECOND_MAX_WINDOWS] = {0, 0, 0, 0};
+    uint32_t ev_off[SECOND_MAX_WINDOWS] = {0, 0, 0, 0}, bc_off[SECOND_MAX_WINDOWS] = {0, 0, 0, 0};
+    // offsets are a pure function of the shape (m, P, limbs per constant)
+    void layout(size_t m, size_t P, size_t nl) {
+        n_windows = 0;
+        uint32_t off = 0;
+        for (int ws : second_windows(m, P)) {
+            const int w = n_windows++;
+            win_start[w] = ws;
+            ev_off[w] = off;
+            off += (uint32_t)((P - m) * m * nl);
+            bc_off[w] = off;
+            off += (uint32_t)(m * m * nl);
+        }
+    }
 };
 template <class H = HFr>
 inline SecondTables build_second_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t P, int impl) {
     const size_t m = d + 1;
     std::vector<H> el = domain_elements<H>(n, n);
     SecondTables T;
-    for (size_t ws = 0; ws + m <= P && T.n_windows < 2; ws += m) {
+    for (int wsi : second_windows(m, P)) {
+        const size_t ws = (size_t)wsi;
         std::vector<H> xs(m);
         for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[ws + i]];
         auto basis = lagrange_basis(xs);
         const int w = T.n_windows++;
-        T.win_start[w] = (int)ws;
+        T.win_start[w] = wsi;
         T.ev_off[w] = (uint32_t)T.words.size();
         for (size_t s = 0; s < P; ++s) {
             if (s >= ws && s < ws + m) continue;
