@@ -429,10 +429,11 @@ ShareErrorCode hbmpc_set_small_call_staging(hbmpc_ctx* ctx, int zero_copy);
  * these sizes anyway); larger calls run one lane per chunk.  0 = always one lane per chunk.  Same results either
  * way (A/B aid). */
 ShareErrorCode hbmpc_set_small_batch_chunks(hbmpc_ctx* ctx, size_t max_chunks);
-/* Chunks that fail the optimistic verification first try two cheap candidates -- the polynomial through the lowest
- * degree+1 senders and the one through the next degree+1 -- and accept one that disagrees with at most
+/* Chunks that fail the optimistic verification first try up to four cheap candidates -- the polynomials through the
+ * lowest degree+1 senders, the next degree+1, the last degree+1 of the OEC prefix and a window straddling the first
+ * two -- and accept one that disagrees with at most
  * min(t, S - (degree+t+1)) of the shares the reference's OEC rounds would look at: that IS the polynomial oec_decode
- * returns (robust_interpolate.rs:579-628; it is unique).  Only what neither resolves runs the OEC/Gao kernel.  A
+ * returns (robust_interpolate.rs:579-628; it is unique).  Only what no candidate resolves runs the OEC/Gao kernel.  A
  * single Byzantine sender is always resolved here.  on = 0 sends every flagged chunk to OEC/Gao (A/B aid; same
  * results, statuses and error codes either way). */
 ShareErrorCode hbmpc_set_second_chance(hbmpc_ctx* ctx, int on);
