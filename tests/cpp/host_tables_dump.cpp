@@ -42,6 +42,21 @@ static int run(size_t n, size_t d, size_t t, const std::vector<size_t>& ids) {
     std::printf("const");
     for (uint32_t x : words) std::printf(" %08x", x);
     std::printf("\n");
+    // the second-chance tables (k_second_chance): window offsets, then every table word in the device-constant form
+    const size_t S = ids.size(), rmax = S > needed ? (t < S - needed ? t : S - needed) : 0;
+    if (rmax >= 1) {
+        const int impl = std::is_same<H, HGl>::value ? IMPL_GOLD : IMPL_U29;
+        const SecondTables T = build_second_tables<H>(ids, n, d, needed + rmax, impl);
+        SecondTables L;
+        L.layout(m, needed + rmax, (size_t)impl_nl(impl));
+        std::printf("second %zu %d", needed + rmax, T.n_windows);
+        for (int w = 0; w < T.n_windows; ++w) {
+            std::printf(" %d", T.win_start[w]);
+            if (L.n_windows != T.n_windows || L.win_start[w] != T.win_start[w] || L.ev_off[w] != T.ev_off[w] || L.bc_off[w] != T.bc_off[w]) return 3;
+        }
+        for (uint32_t x : T.words) std::printf(" %08x", x);
+        std::printf("\n");
+    }
     return 0;
 }
 int main(int argc, char** argv) {

@@ -59,3 +59,40 @@ def test_tables_match_oracle(dump, field, n, d, t, ids):
     else:                                                     # nine 29-bit limbs of a1 * 2^261 mod r (fr_u29.hpp)
         v = a1 * pow(2, 261, P) % P
         assert words == [(v >> (29 * i)) & 0x1FFFFFFF for i in range(9)]
+    # second-chance tables: for every candidate window W the rows L_i^W(x_s) over the other positions of the OEC
+    # prefix, then the coefficient rows of the basis
+    S_cnt = len(ids)
+    rmax = min(t, S_cnt - needed) if S_cnt > needed else 0
+    if rmax < 1:
+        assert "second" not in o
+        return
+    tok = o["second"][0].split()
+    Pfx, nw = int(tok[0]), int(tok[1])
+    starts = [int(x) for x in tok[2:2 + nw]]
+    raw = [int(x, 16) for x in tok[2 + nw:]]
+    assert Pfx == needed + rmax
+    want_starts = []
+    for off in (0, m, Pfx - m, (m + 1) // 2):
+        if off + m <= Pfx and off not in want_starts:
+            want_starts.append(off)
+    assert starts == want_starts
+    nl = 2 if field == "gl" else 9
+    rinv = 1 if field == "gl" else pow(pow(2, 261, P), -1, P)
+    vals = []
+    for i in range(0, len(raw), nl):
+        limbs = raw[i:i + nl]
+        v = (limbs[0] | (limbs[1] << 32)) if field == "gl" else sum(l << (29 * j) for j, l in enumerate(limbs))
+        vals.append(v * rinv % P)
+    want = []
+    for ws in starts:
+        wx = [S.domain_element(n, ids[ws + i]) for i in range(m)]
+        wb = []
+        for i in range(m):
+            co = S.lagrange_interpolate(wx, [1 if j == i else 0 for j in range(m)])
+            wb.append(co + [0] * (m - len(co)))
+        for s in range(Pfx):
+            if ws <= s < ws + m:
+                continue
+            want += [S.p_eval(wb[i], S.domain_element(n, ids[s])) for i in range(m)]
+        want += [wb[i][k] for k in range(m) for i in range(m)]
+    assert vals == want
