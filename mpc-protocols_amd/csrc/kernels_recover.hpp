@@ -292,10 +292,13 @@ HB_DEV typename F::E second_dot(const SecondArgs& a, size_t g, int ws, const uin
     return F::canon_loose(F::acc_reduce(acc));
 }
 template <class F>
-HB_DEV void second_chance_one(const SecondArgs& a, size_t g) {
+HB_DEV void second_chance_one(const SecondArgs& a, size_t g, int& first) {
     using E = typename F::E;
     const int M = a.m;
-    for (int w = 0; w < a.n_windows; ++w) {
+    // liars are usually the same senders in every chunk of a batch: start with the window that resolved this lane's
+    // previous chunk (the order of the candidates cannot change the result -- an accepted one is THE polynomial)
+    for (int i = 0; i < a.n_windows; ++i) {
+        const int w = first + i < a.n_windows ? first + i : first + i - a.n_windows;
         const int ws = a.win_start[w];
         int mism = 0;
         for (int e = 0; e < a.P - M && mism <= a.rmax; ++e) {
@@ -316,6 +319,7 @@ HB_DEV void second_chance_one(const SecondArgs& a, size_t g) {
         if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)len;
         if (a.status) a.status[g] = 1;
         atomicAdd(&a.summary[0], 1u);
+        first = w;
         return;
     }
     a.flagged2[atomicAdd(&a.counters[1], 1u)] = (uint32_t)g;
@@ -364,7 +368,8 @@ __global__ __launch_bounds__(256) void k_second_chance(SecondArgs a) {
         return;
     }
     const size_t step = (size_t)gridDim.x * blockDim.x;
-    for (size_t fi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; fi < count; fi += step) second_chance_one<F>(a, a.flagged[fi]);
+    int first = 0;
+    for (size_t fi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; fi < count; fi += step) second_chance_one<F>(a, a.flagged[fi], first);
 }
 
 }  // namespace hbmpc
