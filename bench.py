@@ -285,6 +285,23 @@ def extra_measurements(eng, torch, dev, stream):
     assert bool((back == y).all()) and int(cst.abs().max()) == 0
     res["codec_unpack_fvec_validated"] = {"ms": ms, "GBps": 2 * 32 * G * n / ms / 1e6}
     del pay, back
+    # the in-place wire path: encode straight into the payload bodies (no pack pass), validate without copying and
+    # decode out of the payloads where they arrived (no unpack pass)
+    wstride = 32 * (G + 1)
+    wire = torch.empty((n * wstride + 64,), dtype=torch.uint8, device=dev)
+    pd = (wire.data_ptr() + 31) // 32 * 32 + 24
+    ms = ev_time(lambda: eng.dev_encode_fvec(x.data_ptr(), G, n, d, pd, wstride, stream))
+    res["wire_encode_in_place"] = {"ms": ms, "note": "vandermonde_apply + pack_fvec in one pass", "payloads": n}
+    ms = ev_time(lambda: eng.dev_validate_fvec(pd, wstride, 8 + 32 * G, G, n, cst.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert int(cst.abs().max()) == 0
+    res["wire_validate_in_place"] = {"ms": ms, "GBps": 32 * G * n / ms / 1e6}
+    ms = ev_time(lambda: eng.dev_batch_recover_slots(ids, ids, pd + 8, wstride // 32, G, n, d, t, co.data_ptr(), nco_d=0,
+                                                     status_d=st.data_ptr(), summary_d=summ.data_ptr(), stream=stream))
+    torch.cuda.synchronize()
+    assert bool((co == x).all()) and int(st.max()) == 0
+    res["wire_decode_in_place"] = {"ms": ms, "recons_per_s": G / ms * 1e3}
+    del wire
     # the same decode with the t lowest-id senders corrupted in 1 % of the chunks (flag + OEC/Gao
     # fallback on the device); results must still be the original polynomials
     gen = torch.Generator(device=dev)

@@ -320,6 +320,29 @@ ShareErrorCode hbmpc_dev_pack_fvec(hbmpc_ctx* ctx, const U256* rows_dev, size_t 
 ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
                                      size_t payload_bytes, size_t G, size_t n_rows, U256* rows_dev, size_t row_stride,
                                      uint32_t* status_dev, void* stream);
+/* In-place wire path -- no pack / unpack pass.  A payload that starts 8 bytes before a 32-byte boundary has its
+ * elements 32-byte aligned, so the encode kernel writes the payload bodies itself and the decode reads them where
+ * they arrived:
+ *   send:    hbmpc_dev_encode_fvec = vandermonde_apply with payload r's body as output row r + the n length prefixes
+ *            (payloads_dev + 8 divisible by 32, payload_stride_bytes a multiple of 32 and >= 8 + 32 G) -- the same
+ *            bytes as vandermonde_apply followed by pack_fvec;
+ *   receive: hbmpc_dev_validate_fvec = unpack_fvec's checks (length prefix, canonical elements; status per payload)
+ *            without the copy, then hbmpc_dev_batch_recover_slots with evals_dev = payloads_dev + 8 bytes,
+ *            row_stride = payload_stride_bytes / 32 and row_slots[i] = the slot (payload index, < 256) of the i-th
+ *            listed sender decodes out of the payloads of the senders that passed (a sender whose payload failed
+ *            is simply not listed; hbmpc_dev_batch_recover_strided is the case row_slots[i] = i).
+ * hbmpc_[gl_]dev_vandermonde_apply_strided is the underlying call: output row j at y_out_dev + j * y_row_stride
+ * elements (y_row_stride >= G). */
+ShareErrorCode hbmpc_dev_vandermonde_apply_strided(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
+                                                   U256* y_out_dev, size_t y_row_stride, void* stream);
+ShareErrorCode hbmpc_dev_encode_fvec(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d, void* payloads_dev,
+                                     size_t payload_stride_bytes, void* stream);
+ShareErrorCode hbmpc_dev_validate_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
+                                       size_t payload_bytes, size_t G, size_t n_rows, uint32_t* status_dev, void* stream);
+ShareErrorCode hbmpc_dev_batch_recover_slots(hbmpc_ctx* ctx, const size_t* sender_ids, const size_t* row_slots, size_t S,
+                                             const U256* evals_dev, size_t row_stride, size_t G, size_t n, size_t d,
+                                             size_t t, int p0_only, U256* out_dev, uint32_t* ncoeffs_out_dev,
+                                             uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
 ShareErrorCode hbmpc_dev_pack_shares(hbmpc_ctx* ctx, const U256* values_dev, size_t N, size_t id, size_t degree,
                                      void* payload_dev, void* stream);
 ShareErrorCode hbmpc_dev_unpack_shares(hbmpc_ctx* ctx, const void* payload_dev, size_t payload_bytes, size_t N, size_t id,
@@ -350,6 +373,8 @@ ShareErrorCode hbmpc_gl_compute_shares_seeded(hbmpc_ctx* ctx, const uint8_t seed
 ShareErrorCode hbmpc_gl_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x, size_t G, size_t n, size_t d, uint64_t* y_out);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
                                               uint64_t* y_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_vandermonde_apply_strided(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
+                                                      uint64_t* y_out_dev, size_t y_row_stride, void* stream);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply_parties(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
                                                       size_t parties, uint64_t* y_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, uint64_t* v_out);

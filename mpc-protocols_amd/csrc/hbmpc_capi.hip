@@ -180,7 +180,10 @@ static ElemConsts elem_consts(int impl, const HFr* c0 = nullptr, const HFr* c1_p
 }
 
 // ---- context -----------------------------------------------------------------------------------
-namespace hbmpc { thread_local unsigned g_eval_parties = 1; }
+namespace hbmpc {
+thread_local unsigned g_eval_parties = 1;
+thread_local size_t g_eval_ystride = 0;
+}
 extern "C" const char* hbmpc_version(void) { return "hbmpc-hip 0.1 (gfx950)"; }
 
 extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out) {
@@ -402,19 +405,22 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
 }
 
 static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y, void* stream,
-                               size_t parties = 1) {
+                               size_t parties = 1, size_t ystride = 0) {
     if (!ctx) return InvalidInput;
     if (parties == 0 || parties > 65535) return fail(ctx, InvalidInput, "parties must be in 1..65535");
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");  // :59-64
     if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
     if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
+    if (ystride != 0 && ystride < G) return fail(ctx, InvalidInput, "output row stride must be >= G");
     if (G == 0) return ShareSuccess;
     if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
     g_eval_parties = (unsigned)parties;  // thread-local: read by the launchers this thread calls next
+    g_eval_ystride = ystride;
     ShareErrorCode rc = eval_impl(ctx, (const uint32_t*)x, G, n, d, (uint32_t*)y, s);
     g_eval_parties = 1;
+    g_eval_ystride = 0;
     if (rc != ShareSuccess) return rc;
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
@@ -1052,6 +1058,49 @@ extern "C" ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payl
     HIP_TRY(ctx, hipMemsetAsync(status_dev, 0, n_rows * 4, s));
     launch_unpack_fvec((const uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n_rows, (uint64_t*)rows_dev, row_stride,
                        status_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+// In-place wire path (no pack / unpack pass): see include/hbmpc_hip.h
+extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_strided(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
+                                                              U256* y_out_dev, size_t y_row_stride, void* stream) {
+    REQ_FR(ctx);
+    return eval_dev(ctx, x_dev, G, n, d, y_out_dev, stream, 1, y_row_stride);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_strided(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n,
+                                                                 size_t d, uint64_t* y_out_dev, size_t y_row_stride,
+                                                                 void* stream) {
+    REQ_GL(ctx);
+    return eval_dev(ctx, x_dev, G, n, d, y_out_dev, stream, 1, y_row_stride);
+}
+extern "C" ShareErrorCode hbmpc_dev_encode_fvec(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
+                                                void* payloads_dev, size_t payload_stride_bytes, void* stream) {
+    REQ_FR(ctx);
+    if (!ctx) return InvalidInput;
+    if (!payloads_dev) return fail(ctx, InvalidInput, "null buffer");
+    if (((uintptr_t)payloads_dev + 8) % 32 || payload_stride_bytes % 32 || payload_stride_bytes < 8 + 32 * G)
+        return fail(ctx, InvalidInput, "payloads must start 8 bytes before a 32-byte boundary, at a stride that is a multiple of 32 and >= 8 + 32 G");
+    ShareErrorCode rc = eval_dev(ctx, x_dev, G, n, d, (char*)payloads_dev + 8, stream, 1, payload_stride_bytes / 32);
+    if (rc != ShareSuccess || G == 0) return rc;
+    launch_fvec_prefix((uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n, pick(ctx, stream));
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_validate_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
+                                                  size_t payload_bytes, size_t G, size_t n_rows, uint32_t* status_dev,
+                                                  void* stream) {
+    REQ_FR(ctx);
+    if (!ctx) return InvalidInput;
+    if (n_rows == 0) return ShareSuccess;
+    if (!payloads_dev || !status_dev) return fail(ctx, InvalidInput, "null buffer");
+    if (payload_bytes < 8 || payload_bytes < 8 + 32 * G)
+        return fail(ctx, InvalidInput, "payload shorter than its length prefix requires");
+    if (payload_stride_bytes % 8 || payload_stride_bytes < payload_bytes || ((uintptr_t)payloads_dev & 7))
+        return fail(ctx, InvalidInput, "payload stride must be 8-byte aligned and >= payload_bytes");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    HIP_TRY(ctx, hipMemsetAsync(status_dev, 0, n_rows * 4, s));
+    launch_validate_fvec((const uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n_rows, status_dev, s);
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }

@@ -54,6 +54,29 @@ __global__ __launch_bounds__(256) void k_unpack_fvec(const uint64_t* __restrict_
     uint64_t* dst = rows + (r * row_stride + g) * 4;
     dst[0] = a0, dst[1] = a1, dst[2] = a2, dst[3] = a3;
 }
+// In-place wire path: when a payload starts 8 bytes before a 32-byte boundary, its elements are 32-byte aligned and
+// the encode kernel writes them directly (output row stride = payload stride); only the length prefixes remain.
+__global__ __launch_bounds__(256) void k_fvec_prefix(uint64_t* __restrict__ payloads, size_t payload_stride_words, size_t G,
+                                                     size_t n_rows) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) payloads[r * payload_stride_words] = (uint64_t)G;
+}
+// k_unpack_fvec without the copy: the receive side decodes out of the payloads in place (sender rows at the payload
+// stride), so deserialisation is only this check -- one read-only pass
+__global__ __launch_bounds__(256) void k_validate_fvec(const uint64_t* __restrict__ payloads, size_t payload_stride_words,
+                                                       size_t G, uint32_t* __restrict__ status) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.y;
+    const uint64_t* p = payloads + r * payload_stride_words;
+    if (p[0] != (uint64_t)G) {
+        if (g == 0) atomicMax(&status[r], 4u);
+        return;
+    }
+    if (g >= G) return;
+    const uint64_t* src = p + 1 + g * 4;
+    const bool bad = !is_canonical_u64x4(src[0], src[1], src[2], src[3]);
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(&status[r], 4u);  // one atomic per wave that saw one
+}
 // values[N] + (id, degree) -> payload = [N][48-byte records]
 __global__ __launch_bounds__(256) void k_pack_shares(const uint64_t* __restrict__ values, size_t N, uint64_t id,
                                                      uint64_t degree, uint64_t* __restrict__ payload) {

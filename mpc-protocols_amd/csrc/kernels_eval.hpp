@@ -11,6 +11,8 @@
 // runs the same 16-point FFT.  Pruning means a multiply only happens where the reference's FFT
 // would multiply two non-trivial values: n=16,d=5 costs 15 modmuls per secret (direct: 80),
 // n=31,d=10 costs 44 per chunk (direct: 341).
+// (ys = elements between consecutive output rows; G when the party rows are dense, larger when they are written
+// straight into wire payloads, hbmpc_dev_encode_fvec.)
 // Layout: input chunk-major x[G][d+1] is staged through LDS with coalesced 16-byte loads (one
 // wave-tile = 64 chunks, rows unpadded: LDS capacity, not LDS bank conflicts, is what matters here);
 // output party-major y[n][G]: a wave stores 2 KiB contiguous per party, each output canonicalised and
@@ -256,7 +258,7 @@ HB_DEV void load_twisted(typename F::E (&X)[16], const uint32_t* __restrict__ ro
 // ---------------------------------------------------------------------------------------------
 template <class F, int LOG, int CNT>
 __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves_min<LOG, CNT>(), F::template eval_waves<LOG, CNT>()))) void k_eval_fft1(const uint32_t* __restrict__ x, size_t G, int n,
-                                                         const uint32_t* __restrict__ tw, uint32_t* __restrict__ y) {
+                                                         const uint32_t* __restrict__ tw, uint32_t* __restrict__ y, size_t ys) {
     using E = typename F::E;
     constexpr int S = 1 << LOG;
     static_assert(CNT <= S && fft_max_vb<LOG, CNT, 1, 1>() <= 64, "bounds");
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
     x += (size_t)blockIdx.y * G * CNT * F::EW;  // party-batched launches: blockIdx.y = party (x[P][G][CNT] -> y[P][n][G])
-    y += (size_t)blockIdx.y * n * G * F::EW;
+    y += (size_t)blockIdx.y * n * ys * F::EW;
     stage_tile<CNT * (F::EW >= 4 ? 2 : 1), F::EW>(lds, x, g0, G, CNT, lane);
     __syncthreads();
     const size_t g = g0 + lane;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
     load_plain<F, LOG, CNT>(X, row, CNT, false, std::make_integer_sequence<int, S>{});
     fft_pruned_sink<F, LOG, CNT, 1, 1>(X, tw, [&](auto idx, const E& v) {
         constexpr int j = decltype(idx)::value;
-        if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, v);
+        if (j < n) F::store_loose(y + ((size_t)j * ys + g) * F::EW, v);
     });
 }
 
@@ -287,7 +289,7 @@ template <class F, int CNT16, bool FOLD>
 __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves_min<4, CNT16 + (FOLD ? 16 : 0)>(), F::template eval_waves<4, CNT16 + (FOLD ? 16 : 0)>()))) void k_eval_fftP(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
                                                          int P, const uint32_t* __restrict__ tw16,
                                                          const uint32_t* __restrict__ twist,
-                                                         uint32_t* __restrict__ y) {
+                                                         uint32_t* __restrict__ y, size_t ys) {
     using E = typename F::E;
     constexpr int Q = FOLD ? 2 : 1;
     static_assert(fft_max_vb<4, CNT16, Q, Q>() <= 64 && fft_max_vb<4, CNT16, Q, 2 * Q>() <= 64, "bounds");
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
     const int lane = threadIdx.x;
     const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
     x += (size_t)blockIdx.y * G * dp1 * F::EW;
-    y += (size_t)blockIdx.y * n * G * F::EW;
+    y += (size_t)blockIdx.y * n * ys * F::EW;
     stage_tile<(FOLD ? 8 : CNT16) * (F::EW >= 4 ? 2 : 1), F::EW>(lds, x, g0, G, dp1, lane);
     __syncthreads();
     const size_t g = g0 + lane;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
         load_plain<F, 4, CNT16>(X, row, dp1, FOLD, std::make_integer_sequence<int, 16>{});
         fft_pruned_sink<F, 4, CNT16, Q, Q>(X, tw16, [&](auto idx, const E& v) {
             const int j = P * decltype(idx)::value;
-            if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, v);
+            if (j < n) F::store_loose(y + ((size_t)j * ys + g) * F::EW, v);
         });
     }
     for (int r = 1; r < P; ++r) {
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
         load_twisted<F, CNT16>(X, row, twist + (size_t)r * dp1 * F::NL, dp1, FOLD, std::make_integer_sequence<int, 16>{});
         fft_pruned_sink<F, 4, CNT16, Q, 2 * Q>(X, tw16, [&](auto idx, const E& v) {
             const int j = r + P * decltype(idx)::value;
-            if (j < n) F::store_loose(y + ((size_t)j * G + g) * F::EW, v);
+            if (j < n) F::store_loose(y + ((size_t)j * ys + g) * F::EW, v);
         });
     }
 }
@@ -327,12 +329,12 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
 // ---------------------------------------------------------------------------------------------
 template <class F>
 __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
-                                                      const uint32_t* __restrict__ alpha, uint32_t* __restrict__ y) {
+                                                      const uint32_t* __restrict__ alpha, uint32_t* __restrict__ y, size_t ys) {
     using E = typename F::E;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
     x += (size_t)blockIdx.y * G * dp1 * F::EW;
-    y += (size_t)blockIdx.y * n * G * F::EW;
+    y += (size_t)blockIdx.y * n * ys * F::EW;
     const uint32_t* row = x + g * (size_t)dp1 * F::EW;
     for (int j = 0; j < n; ++j) {
         const uint32_t* a = alpha + (size_t)j * F::NL;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict
             acc = F::add(acc, F::load(row + (size_t)k * F::EW));
             // value < 3r, limbs < 2^30: fine as the next mulc input
         }
-        F::store_loose(y + ((size_t)j * G + g) * F::EW, acc);
+        F::store_loose(y + ((size_t)j * ys + g) * F::EW, acc);
     }
 }
 
@@ -351,13 +353,13 @@ __global__ __launch_bounds__(256) void k_eval_generic(const uint32_t* __restrict
 // while the call is too small to fill the chip anyway (see k_batch_recover_wide).  Same results as every other path.
 template <class F>
 __global__ __launch_bounds__(256) void k_eval_wide(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
-                                                   const uint32_t* __restrict__ alpha, uint32_t* __restrict__ y) {
+                                                   const uint32_t* __restrict__ alpha, uint32_t* __restrict__ y, size_t ys) {
     using E = typename F::E;
     const int lane = threadIdx.x & 63;
     const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= G) return;
     x += (size_t)blockIdx.y * G * dp1 * F::EW;
-    y += (size_t)blockIdx.y * n * G * F::EW;
+    y += (size_t)blockIdx.y * n * ys * F::EW;
     const uint32_t* row = x + g * (size_t)dp1 * F::EW;
     for (int j = lane; j < n; j += 64) {
         const uint32_t* a = alpha + (size_t)j * F::NL;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_eval_wide(const uint32_t* __restrict__ 
             acc = F::mulc(acc, a);
             acc = F::add(acc, F::load(row + (size_t)k * F::EW));
         }
-        F::store_loose(y + ((size_t)j * G + g) * F::EW, acc);
+        F::store_loose(y + ((size_t)j * ys + g) * F::EW, acc);
     }
 }
 

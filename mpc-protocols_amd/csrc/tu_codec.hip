@@ -28,4 +28,12 @@ void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint3
     hipLaunchKernelGGL(k_poly_degree, dim3((unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1)), dim3(256), 0, s, coeffs, G, m,
                        ew64, degree_out);
 }
+void launch_fvec_prefix(uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, hipStream_t s) {
+    hipLaunchKernelGGL(k_fvec_prefix, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, payloads, payload_stride_words, G, n_rows);
+}
+void launch_validate_fvec(const uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, uint32_t* status,
+                          hipStream_t s) {
+    dim3 grid((unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1), (unsigned)n_rows);
+    hipLaunchKernelGGL(k_validate_fvec, grid, dim3(256), 0, s, payloads, payload_stride_words, G, status);
+}
 }
