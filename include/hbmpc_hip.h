@@ -357,8 +357,8 @@ ShareErrorCode hbmpc_dev_validate_canonical(hbmpc_ctx* ctx, const U256* a_dev, s
  * little-endian elements (what ark serialises for Fp64) instead of U256; same argument meaning, layouts,
  * validation order and error codes.  They need a context created with FieldKind Goldilocks64; a context
  * serves one field only (the other family returns TypeMismatch).  Non-canonical inputs (>= p) are the
- * caller's error, as for Fr.  TruncPr and the wire codec are big-field-only in the reference and have no
- * hbmpc_gl_ form. */
+ * caller's error, as for Fr.  TruncPr is big-field-only in the reference and has no hbmpc_gl_ form; of the wire
+ * codec the in-place Vec<F> path exists for both fields (below). */
 ShareErrorCode hbmpc_gl_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs, size_t B, size_t n, size_t d,
                                        uint64_t* shares_out);
 ShareErrorCode hbmpc_gl_dev_compute_shares(hbmpc_ctx* ctx, const uint64_t* coeffs_dev, size_t B, size_t n, size_t d,
@@ -375,6 +375,16 @@ ShareErrorCode hbmpc_gl_dev_vandermonde_apply(hbmpc_ctx* ctx, const uint64_t* x_
                                               uint64_t* y_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply_strided(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
                                                       uint64_t* y_out_dev, size_t y_row_stride, void* stream);
+/* Goldilocks wire payloads (ark Fp64: u64-LE length + 8-byte LE canonical elements = the in-memory form): any 8-byte-
+ * aligned payload has aligned elements, so the in-place path needs no alignment trick: stride a multiple of 8. */
+ShareErrorCode hbmpc_gl_dev_encode_fvec(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
+                                        void* payloads_dev, size_t payload_stride_bytes, void* stream);
+ShareErrorCode hbmpc_gl_dev_validate_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
+                                          size_t payload_bytes, size_t G, size_t n_rows, uint32_t* status_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_batch_recover_slots(hbmpc_ctx* ctx, const size_t* sender_ids, const size_t* row_slots, size_t S,
+                                                const uint64_t* evals_dev, size_t row_stride, size_t G, size_t n, size_t d,
+                                                size_t t, int p0_only, uint64_t* out_dev, uint32_t* ncoeffs_out_dev,
+                                                uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply_parties(hbmpc_ctx* ctx, const uint64_t* x_dev, size_t G, size_t n, size_t d,
                                                       size_t parties, uint64_t* y_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_make_vandermonde(hbmpc_ctx* ctx, size_t n, size_t d, uint64_t* v_out);

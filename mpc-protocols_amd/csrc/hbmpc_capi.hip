@@ -1073,37 +1073,51 @@ extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_strided(hbmpc_ctx* ctx,
     REQ_GL(ctx);
     return eval_dev(ctx, x_dev, G, n, d, y_out_dev, stream, 1, y_row_stride);
 }
-extern "C" ShareErrorCode hbmpc_dev_encode_fvec(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t n, size_t d,
-                                                void* payloads_dev, size_t payload_stride_bytes, void* stream) {
-    REQ_FR(ctx);
+static ShareErrorCode encode_fvec_any(hbmpc_ctx* ctx, const void* x_dev, size_t G, size_t n, size_t d, void* payloads_dev,
+                                      size_t payload_stride_bytes, void* stream) {
     if (!ctx) return InvalidInput;
     if (!payloads_dev) return fail(ctx, InvalidInput, "null buffer");
-    if (((uintptr_t)payloads_dev + 8) % 32 || payload_stride_bytes % 32 || payload_stride_bytes < 8 + 32 * G)
-        return fail(ctx, InvalidInput, "payloads must start 8 bytes before a 32-byte boundary, at a stride that is a multiple of 32 and >= 8 + 32 G");
-    ShareErrorCode rc = eval_dev(ctx, x_dev, G, n, d, (char*)payloads_dev + 8, stream, 1, payload_stride_bytes / 32);
+    const size_t eb = ebytes(ctx);  // Fr: bodies must be 32-byte aligned; Goldilocks: 8-byte elements, any 8-byte-aligned payload
+    if (((uintptr_t)payloads_dev + 8) % eb || payload_stride_bytes % eb || payload_stride_bytes < 8 + eb * G)
+        return fail(ctx, InvalidInput, eb == 32 ? "payloads must start 8 bytes before a 32-byte boundary, at a stride that is a multiple of 32 and >= 8 + 32 G"
+                                                : "payloads must be 8-byte aligned, at a stride that is a multiple of 8 and >= 8 + 8 G");
+    ShareErrorCode rc = eval_dev(ctx, x_dev, G, n, d, (char*)payloads_dev + 8, stream, 1, payload_stride_bytes / eb);
     if (rc != ShareSuccess || G == 0) return rc;
     launch_fvec_prefix((uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n, pick(ctx, stream));
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_validate_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
-                                                  size_t payload_bytes, size_t G, size_t n_rows, uint32_t* status_dev,
-                                                  void* stream) {
-    REQ_FR(ctx);
+static ShareErrorCode validate_fvec_any(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
+                                        size_t payload_bytes, size_t G, size_t n_rows, uint32_t* status_dev, void* stream) {
     if (!ctx) return InvalidInput;
     if (n_rows == 0) return ShareSuccess;
     if (!payloads_dev || !status_dev) return fail(ctx, InvalidInput, "null buffer");
-    if (payload_bytes < 8 || payload_bytes < 8 + 32 * G)
+    const size_t eb = ebytes(ctx);
+    if (payload_bytes < 8 || payload_bytes < 8 + eb * G)
         return fail(ctx, InvalidInput, "payload shorter than its length prefix requires");
     if (payload_stride_bytes % 8 || payload_stride_bytes < payload_bytes || ((uintptr_t)payloads_dev & 7))
         return fail(ctx, InvalidInput, "payload stride must be 8-byte aligned and >= payload_bytes");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
     HIP_TRY(ctx, hipMemsetAsync(status_dev, 0, n_rows * 4, s));
-    launch_validate_fvec((const uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n_rows, status_dev, s);
+    launch_validate_fvec((const uint64_t*)payloads_dev, payload_stride_bytes / 8, G, n_rows, status_dev, s, is_gold(ctx));
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
+#define TYPED_WIRE(T, REQ, PFX)                                                                                            \
+    extern "C" ShareErrorCode PFX##dev_encode_fvec(hbmpc_ctx* ctx, const T* x_dev, size_t G, size_t n, size_t d,           \
+                                                   void* payloads_dev, size_t payload_stride_bytes, void* stream) {         \
+        REQ(ctx);                                                                                                          \
+        return encode_fvec_any(ctx, x_dev, G, n, d, payloads_dev, payload_stride_bytes, stream);                           \
+    }                                                                                                                      \
+    extern "C" ShareErrorCode PFX##dev_validate_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes, \
+                                                     size_t payload_bytes, size_t G, size_t n_rows, uint32_t* status_dev,  \
+                                                     void* stream) {                                                       \
+        REQ(ctx);                                                                                                          \
+        return validate_fvec_any(ctx, payloads_dev, payload_stride_bytes, payload_bytes, G, n_rows, status_dev, stream);   \
+    }
+TYPED_WIRE(U256, REQ_FR, hbmpc_)
+TYPED_WIRE(uint64_t, REQ_GL, hbmpc_gl_)
 extern "C" ShareErrorCode hbmpc_dev_pack_shares(hbmpc_ctx* ctx, const U256* values_dev, size_t N, size_t id,
                                                 size_t degree, void* payload_dev, void* stream) {
     REQ_FR(ctx);

@@ -77,6 +77,21 @@ __global__ __launch_bounds__(256) void k_validate_fvec(const uint64_t* __restric
     const bool bad = !is_canonical_u64x4(src[0], src[1], src[2], src[3]);
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(&status[r], 4u);  // one atomic per wave that saw one
 }
+// Goldilocks (ark Fp64: 8-byte little-endian canonical elements, the in-memory form): Vec<F> payloads need no
+// alignment trick at all -- any 8-byte-aligned payload has aligned elements
+__global__ __launch_bounds__(256) void k_validate_fvec_gl(const uint64_t* __restrict__ payloads, size_t payload_stride_words,
+                                                          size_t G, uint32_t* __restrict__ status) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t r = blockIdx.y;
+    const uint64_t* p = payloads + r * payload_stride_words;
+    if (p[0] != (uint64_t)G) {
+        if (g == 0) atomicMax(&status[r], 4u);
+        return;
+    }
+    if (g >= G) return;
+    const bool bad = p[1 + g] >= 0xFFFFFFFF00000001ULL;
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(&status[r], 4u);
+}
 // values[N] + (id, degree) -> payload = [N][48-byte records]
 __global__ __launch_bounds__(256) void k_pack_shares(const uint64_t* __restrict__ values, size_t N, uint64_t id,
                                                      uint64_t degree, uint64_t* __restrict__ payload) {

@@ -62,7 +62,7 @@ void launch_pack_fvec(const uint64_t* rows, size_t row_stride, size_t G, size_t 
                       size_t payload_stride_words, hipStream_t s);
 void launch_fvec_prefix(uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, hipStream_t s);
 void launch_validate_fvec(const uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, uint32_t* status,
-                          hipStream_t s);
+                          hipStream_t s, bool gold = false);
 void launch_unpack_fvec(const uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, uint64_t* rows,
                         size_t row_stride, uint32_t* status, hipStream_t s);
 void launch_pack_shares(const uint64_t* values, size_t N, uint64_t id, uint64_t degree, uint64_t* payload, hipStream_t s);

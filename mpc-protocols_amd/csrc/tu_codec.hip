@@ -32,8 +32,9 @@ void launch_fvec_prefix(uint64_t* payloads, size_t payload_stride_words, size_t 
     hipLaunchKernelGGL(k_fvec_prefix, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, payloads, payload_stride_words, G, n_rows);
 }
 void launch_validate_fvec(const uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, uint32_t* status,
-                          hipStream_t s) {
+                          hipStream_t s, bool gold) {
     dim3 grid((unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1), (unsigned)n_rows);
-    hipLaunchKernelGGL(k_validate_fvec, grid, dim3(256), 0, s, payloads, payload_stride_words, G, status);
+    if (gold) hipLaunchKernelGGL(k_validate_fvec_gl, grid, dim3(256), 0, s, payloads, payload_stride_words, G, status);
+    else hipLaunchKernelGGL(k_validate_fvec, grid, dim3(256), 0, s, payloads, payload_stride_words, G, status);
 }
 }

@@ -370,7 +370,7 @@ class Engine:
 
     def dev_batch_recover_slots(self, sender_ids, row_slots, evals_d, row_stride, G, n, d, t, out_d, p0=False, nco_d=0,
                                 status_d=0, summary_d=0, stream=0):
-        return self.L.hbmpc_dev_batch_recover_slots(self.ctx, _p(_sz(sender_ids)), _p(_sz(row_slots)),
+        return self._f("dev_batch_recover_slots")(self.ctx, _p(_sz(sender_ids)), _p(_sz(row_slots)),
                                                     C.c_size_t(len(sender_ids)), C.c_void_p(evals_d), C.c_size_t(row_stride),
                                                     C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(t),
                                                     C.c_int(1 if p0 else 0), C.c_void_p(out_d), C.c_void_p(nco_d),
@@ -405,11 +405,11 @@ class Engine:
                                                         C.c_void_p(y_d), C.c_size_t(y_row_stride), C.c_void_p(stream))
 
     def dev_encode_fvec(self, x_d, G, n, d, payloads_d, payload_stride_bytes, stream=0):
-        return self.L.hbmpc_dev_encode_fvec(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
+        return self._f("dev_encode_fvec")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
                                             C.c_void_p(payloads_d), C.c_size_t(payload_stride_bytes), C.c_void_p(stream))
 
     def dev_validate_fvec(self, payloads_d, payload_stride_bytes, payload_bytes, G, n_rows, status_d, stream=0):
-        return self.L.hbmpc_dev_validate_fvec(self.ctx, C.c_void_p(payloads_d), C.c_size_t(payload_stride_bytes),
+        return self._f("dev_validate_fvec")(self.ctx, C.c_void_p(payloads_d), C.c_size_t(payload_stride_bytes),
                                               C.c_size_t(payload_bytes), C.c_size_t(G), C.c_size_t(n_rows),
                                               C.c_void_p(status_d), C.c_void_p(stream))
 

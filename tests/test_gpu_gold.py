@@ -325,3 +325,39 @@ def test_small_field_triple_gen_pipeline(eng, n, t, groups):
         assert [int(v) for v in c[p]] == [(int(srt[p, i]) + opened[i]) % P for i in range(N)]
     rc, p0, st = eng.batch_recover_p0(list(range(n)), c, n, t, t)
     assert rc == 0 and [int(v) for v in p0] == [x * y % P for x, y in zip(a, b)]
+
+
+def test_in_place_wire_path_small_field(_eng):
+    """ark's Vec<Fp64> payloads (u64-LE length + 8-byte LE elements) written by the encode kernel and decoded where
+    they arrived; a sender with a non-canonical element is dropped, another one lies in one chunk."""
+    import torch
+    eng = _eng
+    n, t, d, G = 10, 3, 3, 501
+    x = rnd(31, G, d + 1)
+    stride = 8 * (G + 3)                                          # any multiple of 8 >= 8 + 8 G
+    dev = torch.device("cuda:0")
+    wire = torch.zeros(n * stride // 8, dtype=torch.int64, device=dev)
+    xd = torch.from_numpy(x.view(np.int64)).to(dev)
+    assert eng.dev_encode_fvec(xd.data_ptr(), G, n, d, wire.data_ptr(), stride) == 0
+    torch.cuda.synchronize()
+    raw = wire.cpu().numpy().view(np.uint64).reshape(n, stride // 8)
+    rc, y = eng.vandermonde_apply(x, n, d)
+    assert rc == 0
+    for j in range(n):
+        assert raw[j, 0] == G and np.array_equal(raw[j, 1:1 + G], y[j])      # Vec<Fp64>::serialize_compressed
+    raw = raw.copy()
+    raw[2, 1 + 7] ^= np.uint64(1)                                # sender 2 lies in chunk 7
+    raw[6, 1 + 11] = np.uint64(P)                                # sender 6: an element == p is not deserialisable
+    wire.copy_(torch.from_numpy(raw.view(np.int64).reshape(-1)))
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    assert eng.dev_validate_fvec(wire.data_ptr(), stride, 8 + 8 * G, G, n, st.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [4 if j == 6 else 0 for j in range(n)]
+    order = [j for j in range(n) if j != 6][::-1]
+    co = torch.zeros((G, d + 1), dtype=torch.int64, device=dev)
+    stat = torch.zeros(G, dtype=torch.uint8, device=dev)
+    assert eng.dev_batch_recover_slots(order, order, wire.data_ptr() + 8, stride // 8, G, n, d, t, co.data_ptr(),
+                                       status_d=stat.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(co.cpu().numpy().view(np.uint64), x)
+    assert int(stat[7]) == 1 and int(stat.sum()) == 1
