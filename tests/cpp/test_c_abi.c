@@ -1,6 +1,7 @@
 /* A plain C99 caller of include/hbmpc_hip.h -- the shape of the reference's own C test of its exported ABI
  * (mpc/src/ffi/tests/secret_share.c: create shares of a literal U256 secret for n = 6 parties, recover, compare),
  * restated against this library's entry points, for both share kinds and both fields.  Needs an MI355X. */
+#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -73,6 +74,50 @@ static int goldilocks_roundtrip(void) {
     return 0;
 }
 
+/* a dealer without a host rng (seeded sharing, secrets drawn too), and the in-place wire path: the encode kernel
+ * writes the n Vec<F> payloads, the receive side validates and decodes out of them where they lie */
+static int seeded_and_wire(hbmpc_ctx* ctx) {
+    enum { N = 7, T = 2, D = 2, B = 40, STRIDE = 32 * (B + 1) };
+    uint8_t seed[32];
+    U256 shares[N * B], again[N * B];
+    size_t ids[N], stats[4];
+    void *buf = NULL;
+    U256 *x_dev, *co_dev;
+    uint32_t* st_dev;
+    uint8_t* wire;
+    uint32_t st[N];
+    U256 x[B * (D + 1)], co[B * (D + 1)];
+    int i;
+    for (i = 0; i < 32; ++i) seed[i] = (uint8_t)(7 * i + 1);
+    for (i = 0; i < N; ++i) ids[i] = (size_t)i;
+    CHECK(hbmpc_compute_shares_seeded(ctx, seed, NULL, B, 0, N, D, shares) == ShareSuccess);
+    CHECK(hbmpc_compute_shares_seeded(ctx, seed, NULL, B, 0, N, D, again) == ShareSuccess);
+    CHECK(memcmp(shares, again, sizeof shares) == 0);                       /* a function of (seed, index) only */
+    CHECK(hbmpc_compute_shares_seeded(ctx, seed, NULL, B, 1, N, D, again) == ShareSuccess);
+    CHECK(memcmp(shares, again, sizeof shares) != 0);
+    /* device side: x[B][D+1] -> n payloads in place -> validate -> decode in place */
+    for (i = 0; i < B * (D + 1); ++i) x[i] = rand_fr();
+    CHECK(hbmpc_dev_alloc(ctx, sizeof x + sizeof co + 64 * sizeof(uint32_t) + (size_t)N * STRIDE + 64, &buf) == ShareSuccess);
+    x_dev = (U256*)buf;
+    co_dev = x_dev + B * (D + 1);
+    st_dev = (uint32_t*)(co_dev + B * (D + 1));
+    wire = (uint8_t*)(st_dev + 64);
+    wire += (32 - ((uintptr_t)wire & 31)) % 32 + 24;                         /* 8 bytes before a 32-byte boundary */
+    CHECK(hbmpc_memcpy_h2d(ctx, x_dev, x, sizeof x, NULL) == ShareSuccess);
+    CHECK(hbmpc_dev_encode_fvec(ctx, x_dev, B, N, D, wire, STRIDE, NULL) == ShareSuccess);
+    CHECK(hbmpc_dev_validate_fvec(ctx, wire, STRIDE, 8 + 32 * B, B, N, st_dev, NULL) == ShareSuccess);
+    CHECK(hbmpc_dev_batch_recover_slots(ctx, ids, ids, N, (const U256*)(wire + 8), STRIDE / 32, B, N, D, T, 0, co_dev, NULL, NULL,
+                                        NULL, NULL) == ShareSuccess);
+    CHECK(hbmpc_memcpy_d2h(ctx, co, co_dev, sizeof co, NULL) == ShareSuccess);
+    CHECK(hbmpc_memcpy_d2h(ctx, st, st_dev, sizeof st, NULL) == ShareSuccess);
+    CHECK(hbmpc_stream_sync(ctx, NULL) == ShareSuccess);
+    for (i = 0; i < N; ++i) CHECK(st[i] == 0);
+    CHECK(memcmp(co, x, sizeof co) == 0);
+    CHECK(hbmpc_cache_stats(ctx, stats) == ShareSuccess && stats[0] > 0 && stats[3] == 0);
+    CHECK(hbmpc_dev_free(ctx, buf) == ShareSuccess);
+    return 0;
+}
+
 int main(void) {
     hbmpc_ctx* ctx = NULL;
     int bad = 0;
@@ -82,6 +127,7 @@ int main(void) {
     }
     bad += robust_roundtrip(ctx);
     bad += nonrobust_roundtrip(ctx);
+    bad += seeded_and_wire(ctx);
     hbmpc_destroy(ctx);
     bad += goldilocks_roundtrip();
     if (bad == 0) printf("C ABI round trips passed (%s)\n", hbmpc_version());
