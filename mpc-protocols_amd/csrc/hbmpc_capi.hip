@@ -36,6 +36,7 @@ struct hbmpc_ctx {
         void* p = nullptr;
         size_t cap = 0;
         bool pinned = false;  // referenced by a captured HIP graph: never freed before hbmpc_destroy
+        bool dirty = true;    // the batch_recover counters at its start are not known to be zero (fresh, or a failed call)
     };
     std::map<std::string, Tab> tables;             // device-resident constant tables
     std::vector<uint32_t*> retired_tables;         // evicted one flush ago; freed at the next flush (see get_table)
@@ -124,7 +125,7 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
 // value an earlier memset/kernel had left there), which silently dropped flagged chunks; ordinary hipMalloc
 // memory is coherent at kernel boundaries.  Calls on one stream are ordered, so they can share a buffer; it
 // only grows (after draining the stream).
-static ShareErrorCode get_scratch(hbmpc_ctx* ctx, hipStream_t s, size_t bytes, void** out) {
+static ShareErrorCode get_scratch(hbmpc_ctx* ctx, hipStream_t s, size_t bytes, void** out, bool* dirty = nullptr) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto& slot = ctx->scratch[s];
     if (slot.cap < bytes) {
@@ -140,8 +141,14 @@ static ShareErrorCode get_scratch(hbmpc_ctx* ctx, hipStream_t s, size_t bytes, v
         slot.cap = want;
     }
     if (g_capturing) slot.pinned = true;
+    if (dirty) *dirty = slot.dirty;
     *out = slot.p;
     return ShareSuccess;
+}
+static void set_scratch_dirty(hbmpc_ctx* ctx, hipStream_t s, bool dirty) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->scratch.find(s);
+    if (it != ctx->scratch.end()) it->second.dirty = dirty;
 }
 static std::string key(const char* kind, std::initializer_list<size_t> v, int impl) {
     std::string k = kind;

@@ -20,6 +20,7 @@
 #include "../../include/hbmpc_hip.h"
 #include "fr_sat.hpp"
 #include "fr_u29.hpp"
+#include "kernels_recover.hpp"  // RowsArg
 
 namespace hbmpc {
 
@@ -33,7 +34,7 @@ struct GaoArgs {
     const uint32_t* evals;     // sender rows, canonical (row s at evals + rows[s] * row_stride * 8 words)
     size_t G;
     size_t row_stride;
-    const int* rows;           // [S] rows[s] = position of the s-th lowest sender id (device)
+    RowsArg rows;              // rows[s] = position of the s-th lowest sender id (kernels_recover.hpp)
     const uint32_t* alpha_s;   // [S] alpha of the s-th lowest sender id, device-constant form
     const GaoRound* rounds;    // [n_rounds]
     int n_rounds;
@@ -50,6 +51,8 @@ struct GaoArgs {
     const uint32_t* one_plain; // limbs of the integer 1 (mont(x, 1) leaves Montgomery form)
     const uint32_t* r2;        // device-constant form of R (mont(x, r2) = x*R)
     const uint32_t* inv_exp;   // r - 2 as 8 x u32
+    uint32_t* reset;           // batch path: the call's four counters ([3] = ticket); the last working block of k_unscale
+                               // zeroes them for the next call
     uint32_t* scales;          // [count][NL + 1]: word 0 = 1 when the chunk's output still carries the factor l^N held in
                                // words 1..NL (Montgomery form); k_unscale divides it out with a batched inversion
 };
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
 // consecutive entries of the flagged list, multiplies their factors together, inverts the product once
 // (Fermat) and peels the individual inverses off again (Montgomery's trick: 3 multiplications per entry).
 template <class F>
-__global__ __launch_bounds__(64) void k_unscale(GaoArgs a) {
+HB_DEV void unscale_lane(const GaoArgs& a) {
     using E = typename F::E;
     constexpr int NL = F::NL, B = 8;
     const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
@@ -387,6 +390,23 @@ __global__ __launch_bounds__(64) void k_unscale(GaoArgs a) {
             const E q = F::cond_sub_r(F::mont(F::load(p), inv_i));             // Q'_k / l^N, Montgomery form
             F::store_lt2r(p, F::cond_sub_r(F::mont(q, a.one_plain)));          // leave Montgomery form
         }
+    }
+}
+template <class F>
+__global__ __launch_bounds__(64) void k_unscale(GaoArgs a) {
+    unscale_lane<F>(a);
+    // Last kernel of a batch_recover call: the block that finishes last leaves the call's counters at zero, which is
+    // what the first kernel of the NEXT call on this stream expects (there is no init launch).  Every lane of a block
+    // -- one wave -- has read its count in the first instruction of unscale_lane, before this lane gets here.
+    if (a.reset && threadIdx.x == 0) {
+        // Only the blocks that own entries of the list (and block 0, so that the quorum is never empty) take a ticket:
+        // an idle block has nothing the reset could disturb -- if it runs late and reads a count that is already
+        // zero it computes quorum 1 and is still idle.  No fence: nothing this block wrote needs publishing before
+        // the ticket, and a working block's reads of the count precede its ticket in program order.
+        const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
+        const size_t per_block = (size_t)blockDim.x * 8;
+        const unsigned quorum = count ? (unsigned)((count + per_block - 1) / per_block) : 1u;
+        if (blockIdx.x < quorum && atomicAdd(&a.reset[3], 1u) == quorum - 1) a.reset[0] = a.reset[1] = a.reset[2] = a.reset[3] = 0u;
     }
 }
 

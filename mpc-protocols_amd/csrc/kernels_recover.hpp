@@ -19,11 +19,20 @@
 
 namespace hbmpc {
 
+// The row permutation (rows[s] = position, in the caller's arrays, of the s-th lowest sender id; S <= n <= 255)
+// travels in the kernel ARGUMENTS of every kernel of a call: no host buffer an async copy would depend on, no cache
+// entry per arrival order (arrival orders change with every reconstruction), graph-capturable, and no init launch.
+struct RowsArg {
+    uint32_t w[64];  // 256 one-byte positions, four to a word: a dynamic index is one scalar dword load + a shift
+    __host__ __device__ int operator[](int s) const { return (int)((w[s >> 2] >> (8 * (s & 3))) & 0xffu); }
+    void set(size_t s, unsigned v) { w[s >> 2] = (w[s >> 2] & ~(0xffu << (8 * (s & 3)))) | ((v & 0xffu) << (8 * (s & 3))); }
+};
+
 struct RecoverArgs {
     const uint32_t* evals;   // sender rows, canonical; row s starts at evals + rows[s] * row_stride * 8 words
     size_t G;
     size_t row_stride;       // elements between consecutive sender rows (G when the rows are dense)
-    const int* rows;         // [S] rows[s] = position (in the caller's arrays) of the s-th lowest sender id (device)
+    RowsArg rows;            // rows[s] = position (in the caller's arrays) of the s-th lowest sender id
     int needed;              // d + t + 1
     int m;                   // d + 1
     const uint32_t* vm;      // [(needed - m)][m] device-constant form
@@ -32,21 +41,13 @@ struct RecoverArgs {
     uint32_t* ncoeffs;       // [G] or null
     uint8_t* status;         // [G] or null
     uint32_t* flagged;       // [G] compact list of failing chunks
-    uint32_t* counters;      // [0] = number of flagged chunks
+    uint32_t* counters;      // [0] = number of flagged chunks (zero when the call starts: the previous call's last kernel
+                             // leaves it so, k_unscale)
+    uint32_t* summary;       // {n_fallback, n_failed, first_failed, first_error}: initialised by block 0 of this kernel
 };
-
-// The row permutation reaches the device through the arguments of a one-block kernel, which also does the
-// per-call initialisation: counters[0..4) = 0, summary = {0, 0, 0xffffffff, 0}.  (S <= n <= 255.)
-struct RowsArg {
-    uint8_t r[256];
-};
-template <int = 0>
-__global__ void k_store_rows(RowsArg a, int* __restrict__ dst, int S, uint32_t* __restrict__ counters,
-                                    uint32_t* __restrict__ summary) {
-    const int i = threadIdx.x;
-    if (i < S) dst[i] = a.r[i];
-    if (i < 4) counters[i] = 0;  // [0] = flagged count ([4..8) may be the local summary)
-    if (i < 4) summary[i] = i == 2 ? 0xffffffffu : 0u;
+// first kernel of a call: nothing else touches the summary before this kernel has finished
+HB_DEV void init_summary(const RecoverArgs& a) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
 }
 
 template <class F>
@@ -106,12 +107,14 @@ template <class F, int M, bool P0_ONLY>
 __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     using E = typename F::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    init_summary(a);
+    const uint32_t *vm, *bc;  // the tables, staged in LDS (the arguments themselves stay untouched in the kernarg segment)
     {
         const int vm_words = (a.needed - M) * M * F::NL, bc_words = (P0_ONLY ? 1 : M) * M * F::NL;
         for (int w = threadIdx.x; w < vm_words; w += 256) tab[w] = a.vm[w];
         for (int w = threadIdx.x; w < bc_words; w += 256) tab[vm_words + w] = a.bc[w];
-        a.vm = tab;
-        a.bc = tab + vm_words;
+        vm = tab;
+        bc = tab + vm_words;
     }
     __syncthreads();
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     for (int i = 0; i < M; ++i) y[i] = F::load(a.evals + ((size_t)a.rows[i] * a.row_stride + gg) * F::EW);
     bool ok = true;
     for (int s = M; s < a.needed; ++s) {
-        const E p = F::cond_sub_r(dot_row<F, M>(y, a.vm + (size_t)(s - M) * M * F::NL));
+        const E p = F::cond_sub_r(dot_row<F, M>(y, vm + (size_t)(s - M) * M * F::NL));
         const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * F::EW);
         ok = ok && F::eq_canon(p, ys);
     }
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     if (!ok) return;
     constexpr int OW = P0_ONLY ? 1 : M;
     for (int k = 0; k < OW; ++k)
-        F::store_lt2r(a.out + (g * OW + k) * F::EW, dot_row<F, M>(y, a.bc + (size_t)k * M * F::NL));
+        F::store_lt2r(a.out + (g * OW + k) * F::EW, dot_row<F, M>(y, bc + (size_t)k * M * F::NL));
     if (a.ncoeffs) a.ncoeffs[g] = M;
 }
 
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
 template <class F, bool P0_ONLY>
 __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
     using E = typename F::E;
+    init_summary(a);
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = g < a.G;
     const size_t gg = live ? g : a.G - 1;
@@ -197,6 +201,7 @@ template <class F, bool P0_ONLY>
 __global__ __launch_bounds__(256) void k_batch_recover_wide(RecoverArgs a) {
     using E = typename F::E;
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+    init_summary(a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t g_raw = (size_t)blockIdx.x * 4 + wave;
     const bool live = g_raw < a.G;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(RecoverArgs a) {
 struct SecondArgs {
     const uint32_t* evals;
     size_t G, row_stride;
-    const int* rows;
+    RowsArg rows;
     int m, P, rmax, n_windows, out_width;
     int win_start[4];
     const uint32_t* ev[4];       // [(P - m)][m] rows L_i(x_s), s ascending over the positions outside the window

@@ -47,7 +47,6 @@ void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, con
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, hipStream_t s);
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);
-void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s);
 // OEC / Gao, matvec
 void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
 void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);

@@ -48,9 +48,6 @@ void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStrea
     else if (impl == 1) hipLaunchKernelGGL((k_second_chance<Sat32>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_second_chance<Gold>), dim3(grid), dim3(256), 0, s, a);
 }
-void launch_store_rows(const RowsArg& rows, int* dst, int S, uint32_t* counters, uint32_t* summary, hipStream_t s) {
-    hipLaunchKernelGGL((k_store_rows<0>), dim3(1), dim3(256), 0, s, rows, dst, S, counters, summary);
-}
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s) {
     const unsigned grid = (unsigned)((S + 255) / 256);
     if (impl == 0) hipLaunchKernelGGL((k_matvec<U29>), dim3(grid), dim3(256), 0, s, lb, y, S, out);
