@@ -406,7 +406,12 @@ __global__ __launch_bounds__(64) void k_unscale(GaoArgs a) {
         const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
         const size_t per_block = (size_t)blockDim.x * 8;
         const unsigned quorum = count ? (unsigned)((count + per_block - 1) / per_block) : 1u;
-        if (blockIdx.x < quorum && atomicAdd(&a.reset[3], 1u) == quorum - 1) a.reset[0] = a.reset[1] = a.reset[2] = a.reset[3] = 0u;
+        if (blockIdx.x < quorum && atomicAdd(&a.reset[3], 1u) == quorum - 1) {
+            // chunks the fused small-batch kernel repaired were tallied in reset[2] (the summary was still being
+            // initialised then); every other writer of the summary finished with the previous kernel
+            if (a.summary && a.reset[2]) a.summary[0] += a.reset[2];
+            a.reset[0] = a.reset[1] = a.reset[2] = a.reset[3] = 0u;
+        }
     }
 }
 

@@ -191,67 +191,6 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
     if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
 }
 
-// Small batches (the regime the protocols really run in: one reconstruction, a few hundred elements per message):
-// with one lane per chunk a call of G chunks occupies G/64 waves and each lane walks all (needed - m + out_width) m
-// products serially -- 55 us for ONE chunk at n = 31.  Here a chunk gets a whole wave and every lane owns one ROW of
-// the tables (a verify row or an output row): latency m products instead of (needed - m + out_width) m, at the price
-// of idle lanes, which is free while the chip is not full.  Same tables, same arithmetic, same results; the chunk's
-// sender values are staged once in the wave's slice of LDS, constants are read per lane.
-template <class F, bool P0_ONLY>
-__global__ __launch_bounds__(256) void k_batch_recover_wide(RecoverArgs a) {
-    using E = typename F::E;
-    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
-    init_summary(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t g_raw = (size_t)blockIdx.x * 4 + wave;
-    const bool live = g_raw < a.G;
-    const size_t g = live ? g_raw : a.G - 1;
-    const int M = a.m, nv = a.needed - M, ow = P0_ONLY ? 1 : M;
-    uint32_t* ys = tile + (size_t)wave * a.needed * F::EW;
-    for (int i = lane; i < a.needed; i += 64) {
-        const uint32_t* src = a.evals + ((size_t)a.rows[i] * a.row_stride + g) * F::EW;
-#pragma unroll
-        for (int w = 0; w < F::EW; ++w) ys[i * F::EW + w] = src[w];
-    }
-    __syncthreads();
-    if (!live) return;
-    auto dot = [&](int r) -> E {  // r < nv: verify row r; else output row r - nv
-        const uint32_t* row = r < nv ? a.vm + (size_t)r * M * F::NL : a.bc + (size_t)(r - nv) * M * F::NL;
-        typename F::Acc acc;
-        F::acc_zero(acc);
-        int pending = 0;
-        for (int i = 0; i < M; ++i) {
-            if (pending == F::MAX_DOT_TERMS) {
-                F::acc_fold(acc);
-                pending = 1;
-            }
-            F::acc_mac(acc, F::load(ys + i * F::EW), row + i * F::NL);
-            ++pending;
-        }
-        F::acc_fold(acc);
-        return F::acc_reduce(acc);
-    };
-    // first sweep: rows lane, of verify and output rows alike (an output row's value waits in registers for the vote)
-    bool bad = false, have = false;
-    E kept = F::zero();
-    if (lane < nv + ow) {
-        kept = dot(lane);
-        if (lane < nv) bad = !F::eq_canon(F::canon_loose(kept), F::load(ys + (M + lane) * F::EW));
-        else have = true;
-    }
-    for (int r = lane + 64; r < nv; r += 64) bad = bad || !F::eq_canon(F::canon_loose(dot(r)), F::load(ys + (M + r) * F::EW));
-    const bool ok = __ballot(bad) == 0;
-    if (lane == 0) {
-        if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
-        if (!ok) a.flagged[atomicAdd(a.counters, 1u)] = (uint32_t)g;
-        else if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
-    }
-    if (!ok) return;
-    if (have) F::store_loose(a.out + (g * (size_t)ow + (lane - nv)) * F::EW, kept);
-    for (int r = lane + 64; r < nv + ow; r += 64)
-        if (r >= nv) F::store_loose(a.out + (g * (size_t)ow + (r - nv)) * F::EW, dot(r));
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Second chance for flagged chunks, before the OEC/Gao kernel.  The reference's fallback (oec_decode,
 // robust_interpolate.rs:579-628) returns THE polynomial of degree <= d that agrees with at least d+t+1 of the first
@@ -333,7 +272,7 @@ HB_DEV void second_chance_one(const SecondArgs& a, size_t g, int& first) {
 // enough to give every chunk a wave -- one lying share in a one-polynomial recover_secret then costs two dot
 // products of latency per candidate instead of a serial walk over (P - m) + m of them.
 template <class F>
-HB_DEV void second_chance_wave(const SecondArgs& a, size_t g) {
+HB_DEV void second_chance_wave(const SecondArgs& a, size_t g, uint32_t* tally = nullptr) {
     using E = typename F::E;
     const int M = a.m, lane = threadIdx.x & 63;
     for (int w = 0; w < a.n_windows; ++w) {
@@ -355,7 +294,9 @@ HB_DEV void second_chance_wave(const SecondArgs& a, size_t g) {
         if (lane == 0) {
             if (a.ncoeffs) a.ncoeffs[g] = nz ? 64u - (uint32_t)__clzll((long long)nz) : 0u;
             if (a.status) a.status[g] = 1;
-            atomicAdd(&a.summary[0], 1u);
+            // fused into the first kernel of the call, the summary is still being initialised by block 0: count in
+            // the scratch tally instead (k_unscale adds it to the summary at the end of the call)
+            atomicAdd(tally ? tally : &a.summary[0], 1u);
         }
         return;
     }
@@ -376,5 +317,78 @@ __global__ __launch_bounds__(256) void k_second_chance(SecondArgs a) {
     int first = 0;
     for (size_t fi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; fi < count; fi += step) second_chance_one<F>(a, a.flagged[fi], first);
 }
+
+// Small batches (the regime the protocols really run in: one reconstruction, a few hundred elements per message):
+// with one lane per chunk a call of G chunks occupies G/64 waves and each lane walks all (needed - m + out_width) m
+// products serially -- 55 us for ONE chunk at n = 31.  Here a chunk gets a whole wave and every lane owns one ROW of
+// the tables (a verify row or an output row): latency m products instead of (needed - m + out_width) m, at the price
+// of idle lanes, which is free while the chip is not full.  Same tables, same arithmetic, same results; the chunk's
+// sender values are staged once in the wave's slice of LDS, constants are read per lane.
+struct WideArgs {
+    RecoverArgs r;
+    SecondArgs sc;  // used when fused != 0
+    int fused;      // a chunk that fails the verification tries the second-chance candidates right here (same wave)
+};
+template <class F, bool P0_ONLY>
+__global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
+    using E = typename F::E;
+    const RecoverArgs& a = wa.r;
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+    init_summary(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t g_raw = (size_t)blockIdx.x * 4 + wave;
+    const bool live = g_raw < a.G;
+    const size_t g = live ? g_raw : a.G - 1;
+    const int M = a.m, nv = a.needed - M, ow = P0_ONLY ? 1 : M;
+    uint32_t* ys = tile + (size_t)wave * a.needed * F::EW;
+    for (int i = lane; i < a.needed; i += 64) {
+        const uint32_t* src = a.evals + ((size_t)a.rows[i] * a.row_stride + g) * F::EW;
+#pragma unroll
+        for (int w = 0; w < F::EW; ++w) ys[i * F::EW + w] = src[w];
+    }
+    __syncthreads();
+    if (!live) return;
+    auto dot = [&](int r) -> E {  // r < nv: verify row r; else output row r - nv
+        const uint32_t* row = r < nv ? a.vm + (size_t)r * M * F::NL : a.bc + (size_t)(r - nv) * M * F::NL;
+        typename F::Acc acc;
+        F::acc_zero(acc);
+        int pending = 0;
+        for (int i = 0; i < M; ++i) {
+            if (pending == F::MAX_DOT_TERMS) {
+                F::acc_fold(acc);
+                pending = 1;
+            }
+            F::acc_mac(acc, F::load(ys + i * F::EW), row + i * F::NL);
+            ++pending;
+        }
+        F::acc_fold(acc);
+        return F::acc_reduce(acc);
+    };
+    // first sweep: rows lane, of verify and output rows alike (an output row's value waits in registers for the vote)
+    bool bad = false, have = false;
+    E kept = F::zero();
+    if (lane < nv + ow) {
+        kept = dot(lane);
+        if (lane < nv) bad = !F::eq_canon(F::canon_loose(kept), F::load(ys + (M + lane) * F::EW));
+        else have = true;
+    }
+    for (int r = lane + 64; r < nv; r += 64) bad = bad || !F::eq_canon(F::canon_loose(dot(r)), F::load(ys + (M + r) * F::EW));
+    const bool ok = __ballot(bad) == 0;
+    if (lane == 0) {
+        if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
+        if (!ok && !wa.fused) a.flagged[atomicAdd(a.counters, 1u)] = (uint32_t)g;
+        else if (ok && a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
+    }
+    if (!ok) {
+        // one launch less for a small batch: resolved chunks are tallied in counters[2], the others go to the
+        // OEC/Gao list (counters[1]) exactly as the separate kernel would leave them
+        if (wa.fused) second_chance_wave<F>(wa.sc, g, a.counters + 2);
+        return;
+    }
+    if (have) F::store_loose(a.out + (g * (size_t)ow + (lane - nv)) * F::EW, kept);
+    for (int r = lane + 64; r < nv + ow; r += 64)
+        if (r >= nv) F::store_loose(a.out + (g * (size_t)ow + (r - nv)) * F::EW, dot(r));
+}
+
 
 }  // namespace hbmpc

@@ -44,7 +44,7 @@ bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipS
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 // small batches: one wave per chunk, one evaluation point / one table row per lane (k_eval_wide, k_batch_recover_wide)
 void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y, hipStream_t s);
-void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, hipStream_t s);
+void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);
 // OEC / Gao, matvec

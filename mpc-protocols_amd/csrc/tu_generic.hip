@@ -1,3 +1,4 @@
+#include <cstring>
 #include "fr_gold.hpp"
 #include "kernels_eval.hpp"
 #include "launchers.hpp"
@@ -29,18 +30,23 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
         else hipLaunchKernelGGL((k_batch_recover_generic<Gold, false>), dim3(grid), dim3(256), 0, s, ra);
     }
 }
-void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, hipStream_t s) {
+void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* sc, hipStream_t s) {
     const unsigned grid = (unsigned)((ra.G + 3) / 4);
     const size_t ew = impl == 2 ? 2 : 8, lds = 4 * (size_t)ra.needed * ew * 4;  // one chunk's sender values per wave
+    WideArgs wa;
+    wa.r = ra;
+    wa.fused = sc != nullptr;
+    if (sc) wa.sc = *sc;
+    else memset(&wa.sc, 0, sizeof wa.sc);
     if (impl == 0) {
-        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<U29, true>), dim3(grid), dim3(256), lds, s, ra);
-        else hipLaunchKernelGGL((k_batch_recover_wide<U29, false>), dim3(grid), dim3(256), lds, s, ra);
+        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<U29, true>), dim3(grid), dim3(256), lds, s, wa);
+        else hipLaunchKernelGGL((k_batch_recover_wide<U29, false>), dim3(grid), dim3(256), lds, s, wa);
     } else if (impl == 1) {
-        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Sat32, true>), dim3(grid), dim3(256), lds, s, ra);
-        else hipLaunchKernelGGL((k_batch_recover_wide<Sat32, false>), dim3(grid), dim3(256), lds, s, ra);
+        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Sat32, true>), dim3(grid), dim3(256), lds, s, wa);
+        else hipLaunchKernelGGL((k_batch_recover_wide<Sat32, false>), dim3(grid), dim3(256), lds, s, wa);
     } else {
-        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Gold, true>), dim3(grid), dim3(256), lds, s, ra);
-        else hipLaunchKernelGGL((k_batch_recover_wide<Gold, false>), dim3(grid), dim3(256), lds, s, ra);
+        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Gold, true>), dim3(grid), dim3(256), lds, s, wa);
+        else hipLaunchKernelGGL((k_batch_recover_wide<Gold, false>), dim3(grid), dim3(256), lds, s, wa);
     }
 }
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s) {
