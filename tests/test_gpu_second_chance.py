@@ -66,8 +66,14 @@ def test_every_liar_pattern(env, n, t, d, present, max_liars, sample):
     for second in (True, False):
         eng.set_second_chance(second)
         results.append(eng.batch_recover(ids, arr, n, d, t))
+    # the same with the lane-per-chunk decode kernel, where the second-chance candidates are a kernel of their own
+    # (the default at this size runs them inside the wave-per-chunk kernel)
     eng.set_second_chance(True)
+    eng.set_small_batch_chunks(0)
+    sep = eng.batch_recover(ids, arr, n, d, t)
+    eng.set_small_batch_chunks(8192)
     (rc1, co1, nco1, st1), (rc0, co0, nco0, st0) = results
+    assert sep[0] == rc1 and all(np.array_equal(u, v) for u, v in zip(sep[1:], (co1, nco1, st1)))
     assert rc1 == rc0 and np.array_equal(st1, st0) and np.array_equal(nco1, nco0)
     good = st1 <= 1
     assert np.array_equal(co1[good], co0[good])
