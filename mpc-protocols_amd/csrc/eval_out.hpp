@@ -1,0 +1,15 @@
+// eval_out.hpp -- where an evaluation launch writes (shared by the launcher declarations and the dispatch templates)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hbmpc {
+
+// where a launch writes: output row j of party p at y + ((p * n + j) * ys + g) elements
+struct EvalOut {
+    uint32_t* y;
+    size_t ys;         // elements between consecutive output rows (0: dense, = G)
+    unsigned parties;  // independent [G][d+1] -> [n][G] problems of the launch (blockIdx.y)
+};
+
+}  // namespace hbmpc

@@ -187,10 +187,6 @@ static ElemConsts elem_consts(int impl, const HFr* c0 = nullptr, const HFr* c1_p
 }
 
 // ---- context -----------------------------------------------------------------------------------
-namespace hbmpc {
-thread_local unsigned g_eval_parties = 1;
-thread_local size_t g_eval_ystride = 0;
-}
 extern "C" const char* hbmpc_version(void) { return "hbmpc-hip 0.1 (gfx950)"; }
 
 extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out) {
@@ -358,12 +354,12 @@ extern "C" void hbmpc_graph_destroy(hbmpc_graph* graph) {
 }
 
 // ---- a3 / a5: evaluation on the domain ---------------------------------------------------------
-static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, uint32_t* y,
+static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, EvalOut y,
                                 hipStream_t s) {
     const size_t size = domain_size(n), dp1 = d + 1;
     const int impl = ctx->impl;
     const bool gold = impl == IMPL_GOLD;
-    if (G * g_eval_parties <= ctx->wide_max_chunks / 4 && !ctx->force_generic) {  // small batch: wave per chunk
+    if (G * y.parties <= ctx->wide_max_chunks / 4 && !ctx->force_generic) {  // small batch: wave per chunk
         const uint32_t* alpha;
         ShareErrorCode rc = get_table(ctx, key("alpha", {n}, impl), [&] {
             return gold ? build_alpha<HGl>(n, impl) : build_alpha<HFr>(n, impl);
@@ -423,11 +419,7 @@ static ShareErrorCode eval_dev(hbmpc_ctx* ctx, const void* x, size_t G, size_t n
     if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
-    g_eval_parties = (unsigned)parties;  // thread-local: read by the launchers this thread calls next
-    g_eval_ystride = ystride;
-    ShareErrorCode rc = eval_impl(ctx, (const uint32_t*)x, G, n, d, (uint32_t*)y, s);
-    g_eval_parties = 1;
-    g_eval_ystride = 0;
+    ShareErrorCode rc = eval_impl(ctx, (const uint32_t*)x, G, n, d, EvalOut{(uint32_t*)y, ystride, (unsigned)parties}, s);
     if (rc != ShareSuccess) return rc;
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;

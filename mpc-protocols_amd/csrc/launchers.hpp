@@ -6,35 +6,36 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "eval_out.hpp"
 #include "kernels_gao.hpp"
 #include "kernels_recover.hpp"
 
 namespace hbmpc {
 
 // single-pass pruned FFT, U29, size = 2^log <= 16, cnt = d+1 coefficients
-bool launch_fft1_lo(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
-bool launch_fft1_16a(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
-bool launch_fft1_16b(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
-bool launch_fft1_16c(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
-bool launch_fft1_16d(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_fft1_lo(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);
+bool launch_fft1_16a(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);
+bool launch_fft1_16b(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);
+bool launch_fft1_16c(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);
+bool launch_fft1_16d(int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);
 // multi-pass (size = 16 P), U29, dp1 <= 32
 bool launch_fftP_a(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
-                   uint32_t* y, hipStream_t s);
+                   EvalOut y, hipStream_t s);
 bool launch_fftP_b(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
-                   uint32_t* y, hipStream_t s);
+                   EvalOut y, hipStream_t s);
 bool launch_fftP_c(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
-                   uint32_t* y, hipStream_t s);
+                   EvalOut y, hipStream_t s);
 bool launch_fftP_d(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
-                   uint32_t* y, hipStream_t s);
+                   EvalOut y, hipStream_t s);
 bool launch_fftP_fold(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
-                      uint32_t* y, hipStream_t s);
+                      EvalOut y, hipStream_t s);
 // Goldilocks instantiations of the same templates
-bool launch_gold_fft1(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, uint32_t* y, hipStream_t s);
+bool launch_gold_fft1(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);
 bool launch_gold_fftP(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
-                      uint32_t* y, hipStream_t s);
+                      EvalOut y, hipStream_t s);
 bool launch_gold_recover(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 // generic Horner evaluation (impl: 0 = U29, 1 = Sat32, 2 = Goldilocks)
-void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y,
+void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y,
                          hipStream_t s);
 // batch recover, U29, register-resident m <= 16
 bool launch_recover_a(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
@@ -43,7 +44,7 @@ bool launch_recover_c(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipS
 bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 // small batches: one wave per chunk, one evaluation point / one table row per lane (k_eval_wide, k_batch_recover_wide)
-void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y, hipStream_t s);
+void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s);
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);

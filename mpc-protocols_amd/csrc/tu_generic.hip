@@ -3,20 +3,18 @@
 #include "kernels_eval.hpp"
 #include "launchers.hpp"
 namespace hbmpc {
-extern thread_local unsigned g_eval_parties;
-extern thread_local size_t g_eval_ystride;
-void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y,
+void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y,
                          hipStream_t s) {
     const unsigned grid = (unsigned)((G + 255) / 256);
-    if (impl == 0) hipLaunchKernelGGL((k_eval_generic<U29>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y, g_eval_ystride ? g_eval_ystride : G);
-    else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y, g_eval_ystride ? g_eval_ystride : G);
-    else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y, g_eval_ystride ? g_eval_ystride : G);
+    if (impl == 0) hipLaunchKernelGGL((k_eval_generic<U29>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
+    else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
+    else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
 }
-void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, uint32_t* y, hipStream_t s) {
+void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s) {
     const unsigned grid = (unsigned)((G + 3) / 4);
-    if (impl == 0) hipLaunchKernelGGL((k_eval_wide<U29>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y, g_eval_ystride ? g_eval_ystride : G);
-    else if (impl == 1) hipLaunchKernelGGL((k_eval_wide<Sat32>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y, g_eval_ystride ? g_eval_ystride : G);
-    else hipLaunchKernelGGL((k_eval_wide<Gold>), dim3(grid, g_eval_parties), dim3(256), 0, s, x, G, n, dp1, alpha, y, g_eval_ystride ? g_eval_ystride : G);
+    if (impl == 0) hipLaunchKernelGGL((k_eval_wide<U29>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
+    else if (impl == 1) hipLaunchKernelGGL((k_eval_wide<Sat32>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
+    else hipLaunchKernelGGL((k_eval_wide<Gold>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
 }
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s) {
     if (impl == 0) {
