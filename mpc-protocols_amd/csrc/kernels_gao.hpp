@@ -17,6 +17,7 @@
 // All LDS-resident coefficients are kept canonical (of Montgomery-form values), so "is zero" and
 // degrees are plain limb tests.
 #pragma once
+#include <algorithm>
 #include "../../include/hbmpc_hip.h"
 #include "fr_sat.hpp"
 #include "fr_u29.hpp"
@@ -142,7 +143,9 @@ HB_DEV int group_max(int v, int* scratch) {
     }
 }
 // Groups stride over the flagged list.
-template <class F, int BLOCK, int SUB>
+// INLINE (small batches): the accepted quotient is un-scaled right here -- one inversion per chunk instead of one per
+// eight, which only matters for long lists -- and this kernel is the last of the call: no k_unscale launch.
+template <class F, int BLOCK, int SUB, bool INLINE = false>
 __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
     using E = typename F::E;
     constexpr int NL = F::NL, NSUB = BLOCK / SUB;
@@ -312,15 +315,23 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
                 // Montgomery-form residues of Q' go out as they are together with l^N, and k_unscale finishes
                 // them -- ONE Fermat inversion per eight chunks there (Montgomery's batching trick) instead of
                 // one single-lane, ~100k-instruction inversion per chunk here, which dominated the fallback.
+                if constexpr (INLINE) {
+                    if (scaled) {  // BC + NL holds l^N (Montgomery form): replace it by its inverse, once per chunk
+                        group_sync<BLOCK, SUB>();
+                        if (tid == 0) lds_put<F>(BC + NL, fr_inverse_mont<F>(lds_get<F>(BC + NL), a.inv_exp, a.r2, a.one_plain));
+                        group_sync<BLOCK, SUB>();
+                    }
+                }
                 if (tid < a.out_width) {
                     E c = F::zero();
                     if (tid <= df) {
                         c = lds_get<F>(fq + tid * NL);
-                        if (!scaled) c = F::cond_sub_r(F::mont(c, a.one_plain));
+                        if (INLINE && scaled) c = F::cond_sub_r(F::mont(c, lds_get<F>(BC + NL)));  // Q'_k / l^N
+                        if (INLINE || !scaled) c = F::cond_sub_r(F::mont(c, a.one_plain));          // leave Montgomery form
                     }
                     F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * F::EW, c);
                 }
-                if (tid == 0) {
+                if (!INLINE && tid == 0) {
                     uint32_t* sc = a.scales + fi * (size_t)(NL + 1);
                     sc[0] = scaled ? 1u : 0u;
                     if (scaled) lds_put<F>(sc + 1, lds_get<F>(BC + NL));
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             F::store_lt2r(a.out + (g * (size_t)a.out_width + tid) * F::EW, F::zero());
         }
         if (tid == 0) {
-            if (result != ShareSuccess) a.scales[fi * (size_t)(NL + 1)] = 0u;
+            if (!INLINE && result != ShareSuccess) a.scales[fi * (size_t)(NL + 1)] = 0u;
             if (a.ncoeffs) a.ncoeffs[g] = result == ShareSuccess ? (uint32_t)out_len : 0u;
             if (a.status) a.status[g] = result == ShareSuccess ? 1 : (uint8_t)result;
             if (a.summary) {
@@ -347,6 +358,17 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
             }
         }
         group_sync<BLOCK, SUB>();
+    }
+    if constexpr (INLINE) {
+        // last kernel of the call: the last block that owns list entries leaves the counters at zero (see k_unscale)
+        __syncthreads();
+        if (a.reset && threadIdx.x == 0) {
+            const unsigned quorum = count ? (unsigned)std::min<size_t>((count + NSUB - 1) / NSUB, gridDim.x) : 1u;
+            if (blockIdx.x < quorum && atomicAdd(&a.reset[3], 1u) == quorum - 1) {
+                if (a.summary && a.reset[2]) atomicAdd(&a.summary[0], a.reset[2]);
+                a.reset[0] = a.reset[1] = a.reset[2] = a.reset[3] = 0u;
+            }
+        }
     }
 }
 

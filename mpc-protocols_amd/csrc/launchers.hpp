@@ -49,9 +49,9 @@ void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondA
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);
 // OEC / Gao, matvec
-void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
-void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
-void launch_gao_gold(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s);
+void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s, bool inline_unscale);
+void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s, bool inline_unscale);
+void launch_gao_gold(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s, bool inline_unscale);
 void launch_matvec(int impl, const uint32_t* lb, const uint32_t* y, int S, uint32_t* out, hipStream_t s);
 
 // seeded coefficient generation (kernels_rng.hpp); ew = u32 words per element
