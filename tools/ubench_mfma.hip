@@ -1,0 +1,219 @@
+// ubench_mfma.hip -- go / no-go microbenchmark for the matrix-core formulation of the constant-matrix maps
+// (VERDICT r1 item 2): runs csrc/kernels_mfma.hpp at the BASELINE shapes on random data, checks sampled chunks against
+// host field arithmetic (HFr), and prints ms per launch.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_mfma.hip -o tools/ubench_mfma
+//   tools/ubench_mfma [log2_chunks=20] [reps=20]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <random>
+#include <vector>
+
+#include "../mpc-protocols_amd/csrc/kernels_mfma.hpp"
+#include "../mpc-protocols_amd/csrc/tables_mfma.hpp"
+
+using namespace hbmpc;
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e)); \
+            exit(2);                                                               \
+        }                                                                          \
+    } while (0)
+
+static std::mt19937_64 rng(0xC0FFEE02);
+static void rand_canon(uint64_t c[4]) {
+    for (;;) {
+        for (int i = 0; i < 4; ++i) c[i] = rng();
+        c[3] &= 0x7fffffffffffffffULL;
+        if (!HFr::geq(c)) return;
+    }
+}
+static HFr rand_fr() {
+    uint64_t c[4];
+    rand_canon(c);
+    return HFr::from_canon(c);
+}
+
+template <class F>
+static float time_ms(F f, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+template <int M, int CG>
+static void launch_eval(const mf::MfmaEvalArgs& a) {
+    const size_t per = 128 * CG;
+    hipLaunchKernelGGL((mf::k_mfma_eval<M, CG>), dim3((unsigned)((a.G + per - 1) / per)), dim3(256), 2 * (M * 1024 + 128), 0, a);
+}
+template <int M, int CG, bool P0>
+static void launch_rec(const mf::MfmaRecoverArgs& a) {
+    const size_t per = 128 * CG;
+    hipLaunchKernelGGL((mf::k_mfma_recover<M, CG, P0>), dim3((unsigned)((a.G + per - 1) / per)), dim3(256), 2 * (M * 1024 + 128), 0, a);
+}
+
+// encode x[G][M] with [I ; Cv] -> evals[M + nv][G]; decode with verify rows Cv and output rows Co; check vs host
+template <int M, int CG>
+static int run_shape(const char* name, int nv, size_t G, int reps) {
+    std::vector<std::vector<HFr>> Cv(nv, std::vector<HFr>(M)), Co(M, std::vector<HFr>(M)), Cenc;
+    for (auto& row : Cv)
+        for (auto& v : row) v = rand_fr();
+    for (auto& row : Co)
+        for (auto& v : row) v = rand_fr();
+    for (int i = 0; i < M; ++i) {
+        std::vector<HFr> row(M, HFr::zero());
+        row[i] = HFr::one();
+        Cenc.push_back(row);
+    }
+    for (auto& row : Cv) Cenc.push_back(row);
+    std::vector<std::vector<HFr>> Cdec = Cv;
+    for (auto& row : Co) Cdec.push_back(row);
+    std::vector<std::vector<HFr>> Cp0 = Cv;
+    Cp0.push_back(Co[0]);
+    const int n = M + nv;
+    auto tenc = build_mfma_table(Cenc, M), tdec = build_mfma_table(Cdec, M), tp0 = build_mfma_table(Cp0, M);
+    uint8_t *d_tenc, *d_tdec, *d_tp0, *d_x, *d_y, *d_out, *d_st;
+    uint32_t *d_flag, *d_cnt, *d_sum;
+    CK(hipMalloc(&d_tenc, tenc.size() * 4));
+    CK(hipMalloc(&d_tdec, tdec.size() * 4));
+    CK(hipMalloc(&d_tp0, tp0.size() * 4));
+    CK(hipMemcpy(d_tenc, tenc.data(), tenc.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_tdec, tdec.data(), tdec.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_tp0, tp0.data(), tp0.size() * 4, hipMemcpyHostToDevice));
+    std::vector<uint64_t> x(G * M * 4);
+    for (size_t i = 0; i < G * M; ++i) rand_canon(&x[4 * i]);
+    // edge values in the first chunks: 0, r - 1, 1, 2^255-ish patterns
+    {
+        const uint64_t rm1[4] = {HFr::MOD[0] - 1, HFr::MOD[1], HFr::MOD[2], HFr::MOD[3]};
+        for (int i = 0; i < M; ++i) {
+            for (int k = 0; k < 4; ++k) x[(0 * M + i) * 4 + k] = 0;
+            for (int k = 0; k < 4; ++k) x[(1 * M + i) * 4 + k] = rm1[k];
+            for (int k = 0; k < 4; ++k) x[(2 * M + i) * 4 + k] = k == 0 ? 1 : 0;
+            for (int k = 0; k < 4; ++k) x[(3 * M + i) * 4 + k] = (i & 1) ? rm1[k] : 0;
+        }
+    }
+    CK(hipMalloc(&d_x, G * M * 32));
+    CK(hipMalloc(&d_y, (size_t)n * G * 32));
+    CK(hipMalloc(&d_out, G * M * 32));
+    CK(hipMalloc(&d_st, G));
+    CK(hipMalloc(&d_flag, G * 4));
+    CK(hipMalloc(&d_cnt, 16));
+    CK(hipMalloc(&d_sum, 16));
+    CK(hipMemcpy(d_x, x.data(), G * M * 32, hipMemcpyHostToDevice));
+    CK(hipMemset(d_cnt, 0, 16));
+    mf::MfmaEvalArgs ea = {d_x, G, d_tenc, n, d_y, G};
+    launch_eval<M, CG>(ea);
+    CK(hipDeviceSynchronize());
+    int errors = 0;
+    // sample chunks
+    std::vector<size_t> samp;
+    for (size_t gidx = 0; gidx < 64 && gidx < G; ++gidx) samp.push_back(gidx);
+    for (int k = 0; k < 512; ++k) samp.push_back(rng() % G);
+    for (size_t gidx = G > 64 ? G - 64 : 0; gidx < G; ++gidx) samp.push_back(gidx);
+    std::vector<uint64_t> yrow(4);
+    for (size_t gi : samp) {
+        HFr xv[M];
+        for (int i = 0; i < M; ++i) xv[i] = HFr::from_canon(&x[(gi * M + i) * 4]);
+        for (int s = 0; s < n; ++s) {
+            HFr acc = HFr::zero();
+            for (int i = 0; i < M; ++i) acc = acc + Cenc[s][i] * xv[i];
+            uint64_t want[4];
+            acc.to_canon(want);
+            CK(hipMemcpy(yrow.data(), d_y + ((size_t)s * G + gi) * 32, 32, hipMemcpyDeviceToHost));
+            if (memcmp(want, yrow.data(), 32) != 0 && errors++ < 5)
+                fprintf(stderr, "%s: encode mismatch chunk %zu row %d: got %016llx.. want %016llx..\n", name, gi, s,
+                        (unsigned long long)yrow[0], (unsigned long long)want[0]);
+        }
+    }
+    // corrupt two chunks: one in a verify row, one in an interpolation row
+    const size_t bad1 = G / 3, bad2 = G / 2 + 1;
+    {
+        uint64_t v[4];
+        CK(hipMemcpy(v, d_y + ((size_t)(M + 1) * G + bad1) * 32, 32, hipMemcpyDeviceToHost));
+        v[0] ^= 1;
+        CK(hipMemcpy(d_y + ((size_t)(M + 1) * G + bad1) * 32, v, 32, hipMemcpyHostToDevice));
+        CK(hipMemcpy(v, d_y + ((size_t)2 * G + bad2) * 32, 32, hipMemcpyDeviceToHost));
+        v[3] ^= 1ull << 40;
+        CK(hipMemcpy(d_y + ((size_t)2 * G + bad2) * 32, v, 32, hipMemcpyHostToDevice));
+    }
+    mf::MfmaRecoverArgs ra = {};
+    ra.evals = d_y, ra.G = G, ra.row_stride = G, ra.needed = n, ra.table = d_tdec, ra.out = (uint32_t*)d_out;
+    ra.status = d_st, ra.flagged = d_flag, ra.counters = d_cnt, ra.summary = d_sum;
+    for (int s = 0; s < n; ++s) ra.rows.set(s, s);
+    CK(hipMemset(d_out, 0xEE, G * M * 32));
+    launch_rec<M, CG, false>(ra);
+    CK(hipDeviceSynchronize());
+    uint32_t cnt[4];
+    CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> st(G);
+    CK(hipMemcpy(st.data(), d_st, G, hipMemcpyDeviceToHost));
+    size_t nbad = 0;
+    for (size_t gi = 0; gi < G; ++gi) nbad += st[gi] != 0;
+    if (cnt[0] != 2 || nbad != 2 || st[bad1] != 0xff || st[bad2] != 0xff) {
+        fprintf(stderr, "%s: flagged %u, status!=0 on %zu chunks (expected exactly the 2 corrupted)\n", name, cnt[0], nbad);
+        ++errors;
+    }
+    std::vector<uint64_t> orow(4 * M);
+    for (size_t gi : samp) {
+        if (gi == bad1 || gi == bad2) continue;
+        HFr xv[M];
+        for (int i = 0; i < M; ++i) xv[i] = HFr::from_canon(&x[(gi * M + i) * 4]);
+        CK(hipMemcpy(orow.data(), d_out + gi * M * 32, M * 32, hipMemcpyDeviceToHost));
+        for (int k = 0; k < M; ++k) {
+            HFr acc = HFr::zero();
+            for (int i = 0; i < M; ++i) acc = acc + Co[k][i] * xv[i];
+            uint64_t want[4];
+            acc.to_canon(want);
+            if (memcmp(want, &orow[4 * k], 32) != 0 && errors++ < 5)
+                fprintf(stderr, "%s: decode mismatch chunk %zu coeff %d\n", name, gi, k);
+        }
+    }
+    // restore the corrupted values so the timed decode takes the optimistic path everywhere
+    launch_eval<M, CG>(ea);
+    CK(hipMemset(d_cnt, 0, 16));
+    CK(hipDeviceSynchronize());
+    const float ms_enc = time_ms([&] { launch_eval<M, CG>(ea); }, reps);
+    const float ms_dec = time_ms([&] { launch_rec<M, CG, false>(ra); }, reps);
+    mf::MfmaRecoverArgs rp = ra;
+    rp.table = d_tp0;
+    const float ms_p0 = time_ms([&] { launch_rec<M, CG, true>(rp); }, reps);
+    CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+    if (cnt[0] != 0) {
+        fprintf(stderr, "%s: %u chunks flagged in the clean timed runs\n", name, cnt[0]);
+        ++errors;
+    }
+    const double enc_b = (double)(M + n) * 32 * G, dec_b = (double)(n + M) * 32 * G, p0_b = (double)(n + 1) * 32 * G;
+    printf("{\"shape\": \"%s\", \"M\": %d, \"rows_verify\": %d, \"CG\": %d, \"chunks\": %zu, \"errors\": %d, "
+           "\"encode_%d_rows_ms\": %.4f, \"encode_GBps\": %.0f, \"decode_ms\": %.4f, \"decode_GBps\": %.0f, "
+           "\"decode_p0_ms\": %.4f, \"decode_p0_GBps\": %.0f}\n",
+           name, M, nv, CG, G, errors, n, ms_enc, enc_b / ms_enc / 1e6, ms_dec, dec_b / ms_dec / 1e6, ms_p0, p0_b / ms_p0 / 1e6);
+    fflush(stdout);
+    for (void* q : {(void*)d_tenc, (void*)d_tdec, (void*)d_tp0, (void*)d_x, (void*)d_y, (void*)d_out, (void*)d_st, (void*)d_flag, (void*)d_cnt, (void*)d_sum}) (void)hipFree(q);
+    return errors;
+}
+
+int main(int argc, char** argv) {
+    const int lg = argc > 1 ? atoi(argv[1]) : 20;
+    const int reps = argc > 2 ? atoi(argv[2]) : 20;
+    const size_t G = (size_t)1 << lg;
+    int errors = 0;
+    // ragged small case first (live masks, partial tiles)
+    errors += run_shape<11, 2>("cfg3_ragged", 10, 1000 + 37, 2);
+    errors += run_shape<11, 1>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    errors += run_shape<11, 2>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    errors += run_shape<6, 2>("cfg2-like m=6, 10 extra rows", 10, G, reps);
+    errors += run_shape<6, 4>("cfg2-like m=6, 10 extra rows", 10, G, reps);
+    fprintf(stderr, errors ? "FAILED: %d errors\n" : "all checks passed\n", errors);
+    return errors != 0;
+}
