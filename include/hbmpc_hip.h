@@ -446,6 +446,17 @@ ShareErrorCode hbmpc_gl_dev_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, c
 /* ---- A/B aid: 0 = unsaturated 9x29-bit limbs (default, fast), 1 = saturated 8x32-bit limbs
  * (the straightforward formulation; same results, kept as a cross-check). */
 ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
+/* Large bls12-381 Fr decodes (batch_recover* of at least min_chunks chunks, 2 <= d + 1 <= 15, d + t + 1 - (d + 1)
+ * verify rows that fit one CU's LDS) run the verify and coefficient rows on the matrix cores: every row is a constant
+ * vector (a function of n, d, t and the sender ids) times batch data, i.e. an int8 GEMM over the bytes of the canonical
+ * elements followed by one carry pass and one small-quotient reduction (csrc/kernels_mfma.hpp).  Results are
+ * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both).
+ * min_chunks = 0 keeps the current threshold (default 65536: a sender set not seen before costs ~1 ms of host
+ * table construction). */
+ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);
+/* test aid: workgroups of a matrix-core launch (0 = one per CU, the default); a small number makes a small batch walk
+ * the multi-tile loop of every wave */
+ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups);
 /* test aid: 1 = route every shape through the generic (runtime-shaped) kernels */
 ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
 /* The device-table cache of a context (twiddles, Vandermonde rows, one Lagrange/verify table and one OEC/Gao table

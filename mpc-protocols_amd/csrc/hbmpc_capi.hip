@@ -18,6 +18,8 @@
 #include "kernels_elem.hpp"
 #include "launchers.hpp"
 #include "tables.hpp"
+#include "tables_mfma.hpp"
+#include "kernels_mfma.hpp"
 
 using namespace hbmpc;
 
@@ -46,6 +48,10 @@ struct hbmpc_ctx {
     size_t wide_max_chunks = 8192;                 // batch_recover calls up to this many chunks (evaluations: a quarter of it) use the wave-per-chunk kernels
     bool second_chance = true;                     // flagged chunks try two cheap interpolation candidates before OEC/Gao
     bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
+    bool matrix_cores = true;                      // large Fr decodes run the int8 MFMA formulation (kernels_mfma.hpp)
+    size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
+    int n_cus = 256;
+    int mfma_wgs = 0;                              // test aid: workgroups of a matrix-core launch (0 = one per CU)
     std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
     std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
     std::vector<std::pair<void*, size_t>> stage_free;  // device staging buffers of the host-pointer API, kept between calls
@@ -208,6 +214,10 @@ extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_c
     const char* env = getenv("HBMPC_FIELD_IMPL");
     if (env && std::string(env) == "sat32") ctx->impl = IMPL_SAT32;
     if (field_kind == Goldilocks64) ctx->impl = IMPL_GOLD;
+    env = getenv("HBMPC_MATRIX_CORES");
+    if (env && std::string(env) == "0") ctx->matrix_cores = false;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->n_cus = prop.multiProcessorCount;
     *ctx_out = ctx;
     return ShareSuccess;
 }
@@ -229,6 +239,18 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
     REQ_FR(ctx);
     ctx->impl = impl;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks) {
+    if (!ctx) return InvalidInput;
+    REQ_FR(ctx);
+    ctx->matrix_cores = on != 0;
+    if (min_chunks) ctx->mfma_min_chunks = min_chunks;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups) {
+    if (!ctx || workgroups < 0) return InvalidInput;
+    ctx->mfma_wgs = workgroups;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_small_batch_chunks(hbmpc_ctx* ctx, size_t max_chunks) {

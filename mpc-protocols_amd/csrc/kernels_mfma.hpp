@@ -8,14 +8,19 @@
 // K = 32 bytes of one input element, so an output element of a chunk costs m MFMAs per 32 chunks.  A lane pair
 // (c, h = 0 / 1) holds the 32 digit sums of chunk c: digits 16 h .. 16 h + 15 in the 16 accumulator registers, i.e.
 // each lane owns one 128-bit half of the 256-bit result.  The epilogue stays in registers:
-//   gather    digits (< 2^25, spaced 8 bits) -> 4 x 32-bit words + carry per half (16 v_mad_u64_u32)
+//   gather    digits (< 2^24, spaced 8 bits) -> 4 x 32-bit words + carry per half (8 v_lshl_add_u32, 4 v_mad_u64_u32,
+//             one 128-bit add)
 //   verify    r = 1 (mod 2^32), so  S = y + q r  <=>  q = (S - y) mod 2^32  and  S + q (2^256 - r) = y + q 2^256:
 //             one 4-word multiply-add chain per half, exact, no quotient estimate and no conditional subtraction
 //   reduce    q' = floor(top 49 bits / (r >> 224) + 1) <= q, R = S - q' r; R < r whenever word 8 cancels and the top
 //             word is below r's top word; the (rare) rest takes a wave-uniform slow path of conditional subtractions
 // Carries cross from the low half to the high half once per chain (v_permlane32_swap).
-// The table row of the current output streams through LDS (double buffered, one barrier per output row); a workgroup
-// of 4 waves x CG tiles re-uses it for 128 CG chunks.
+// Table rows are RESIDENT in LDS for the lifetime of a workgroup (one workgroup per CU, up to 160 KB = 13 rows at
+// m = 11): the rows of a call are cut into row groups ("roles"), the grid is divided among the roles in proportion to
+// their rows, and every wave walks 32-chunk tiles in a grid-stride loop with no barrier after the table load.  A first
+// version streamed the current row through a double-buffered LDS slot with one barrier per row: every interval then
+// waited for one L2 round trip of the next row's loads (measured 2.3 us per interval, 0.41 ms for config 3 whatever
+// was removed from the interval -- profiles/r02_ubench_mfma_v2_streaming_ablation.txt).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,7 +45,7 @@ constexpr uint32_t Q_RECIP = 0x8d54253au; // floor(2^62 / (R_TOP + 1))
 struct Half {
     uint32_t nr[4], rw[4];  // this lane half's words of 2^256 - r and of r
     uint32_t hmask;         // all ones in the high half
-    uint32_t k8, k16, k24;  // 2^8, 2^16, 2^24 kept opaque so that the gather stays v_mad_u64_u32
+    uint32_t k16;           // 2^16 kept opaque so that the gather stays v_mad_u64_u32
 };
 HB_DEV Half make_half(int h) {
     Half H;
@@ -50,9 +55,9 @@ HB_DEV Half make_half(int h) {
         H.rw[j] = h ? R_W[4 + j] : R_W[j];
     }
     H.hmask = h ? 0xffffffffu : 0u;
-    uint32_t a = 1u << 8, b = 1u << 16, c = 1u << 24;
-    asm volatile("" : "+s"(a), "+s"(b), "+s"(c));
-    H.k8 = a, H.k16 = b, H.k24 = c;
+    uint32_t b = 1u << 16;
+    asm volatile("" : "+s"(b));
+    H.k16 = b;
     return H;
 }
 // v_permlane32_swap vdst, src0 exchanges lanes 32..63 of vdst with lanes 0..31 of src0; with both = x the first
@@ -60,66 +65,63 @@ HB_DEV Half make_half(int h) {
 HB_DEV uint32_t low_bcast(uint32_t x) { return (uint32_t)__builtin_amdgcn_permlane32_swap(x, x, false, false)[0]; }
 HB_DEV uint32_t high_bcast(uint32_t x) { return (uint32_t)__builtin_amdgcn_permlane32_swap(x, x, false, false)[1]; }
 
-// 16 digit sums (non-negative, < 2^29, weight 2^(8 b)) -> 4 words + carry out of this half
-HB_DEV void gather(const v16i& acc, uint32_t (&W)[4], uint32_t& cout, const Half& H) {
-    uint64_t c = 0;
+// The epilogue works on UN-NORMALISED 64-bit words: T[j] = digits 4j .. 4j+3 of this half combined (two digits fit
+// 32 bits, v_lshl_add_u32; two such pairs fit one v_mad_u64_u32), so T[j] < 2^48 overlaps T[j+1] by its high word.
+// The quotient product is added on top with the words as the 64-bit addend of the multiply-add, and carries are
+// resolved ONCE, by one v_add_co / v_addc chain over the low and high words.
+HB_DEV void gather(const v16i& acc, uint64_t (&T)[4], const Half& H) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        c += (uint32_t)acc[4 * j];
-        c = (uint64_t)(uint32_t)acc[4 * j + 1] * H.k8 + c;
-        c = (uint64_t)(uint32_t)acc[4 * j + 2] * H.k16 + c;
-        c = (uint64_t)(uint32_t)acc[4 * j + 3] * H.k24 + c;
-        W[j] = (uint32_t)c;
-        c >>= 32;
+        const uint32_t p0 = ((uint32_t)acc[4 * j + 1] << 8) + (uint32_t)acc[4 * j];
+        const uint32_t p1 = ((uint32_t)acc[4 * j + 3] << 8) + (uint32_t)acc[4 * j + 2];
+        T[j] = (uint64_t)p1 * H.k16 + p0;
     }
-    cout = (uint32_t)c;
 }
-// U = S + q (2^256 - r), S given as the un-rippled halves (W, cg).  On return the high half holds words 4..7 of U and
-// `top` = everything above 2^256; the low half words 0..3.
-HB_DEV void add_q_nr(uint32_t q, const uint32_t (&W)[4], uint32_t cg, uint32_t (&U)[4], uint32_t& top, const Half& H) {
-    uint64_t a = 0;
+// U = S + q (2^256 - r) for S = sum T[j] 2^(32 j) of both halves.  On return the high half holds words 4..7 of U and
+// `top` = everything above 2^256; the low half words 0..3 (its `top` already handed to the high half).
+HB_DEV void add_q_nr(uint32_t q, const uint64_t (&T)[4], uint32_t (&U)[4], uint32_t& top, const Half& H) {
+    uint64_t Q[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a = (uint64_t)q * H.nr[j] + a;
-        a += W[j];
-        U[j] = (uint32_t)a;
-        a >>= 32;
-    }
-    top = cg + (uint32_t)a;
+    for (int j = 0; j < 4; ++j) Q[j] = (uint64_t)q * H.nr[j] + T[j];
+    uint32_t c;
+    U[0] = (uint32_t)Q[0];
+    U[1] = __builtin_addc((uint32_t)Q[1], (uint32_t)(Q[0] >> 32), 0u, &c);
+    U[2] = __builtin_addc((uint32_t)Q[2], (uint32_t)(Q[1] >> 32), c, &c);
+    U[3] = __builtin_addc((uint32_t)Q[3], (uint32_t)(Q[2] >> 32), c, &c);
+    top = (uint32_t)(Q[3] >> 32) + c;
     const uint32_t cin = low_bcast(top) & H.hmask;
-    uint64_t t = (uint64_t)U[0] + cin;
-    U[0] = (uint32_t)t;
-#pragma unroll
-    for (int j = 1; j < 4; ++j) {
-        t = (t >> 32) + U[j];
-        U[j] = (uint32_t)t;
-    }
-    top += (uint32_t)(t >> 32);
+    U[0] = __builtin_addc(U[0], cin, 0u, &c);
+    U[1] = __builtin_addc(U[1], 0u, c, &c);
+    U[2] = __builtin_addc(U[2], 0u, c, &c);
+    U[3] = __builtin_addc(U[3], 0u, c, &c);
+    top += c;
 }
 // nonzero in some lane of the pair iff  sum != ys (mod r);  ys = this half's 4 words of the claimed value (canonical)
 HB_DEV uint32_t verify_tile(const v16i& acc, const v4i& ys, const Half& H) {
-    uint32_t W[4], cg, U[4], top;
-    gather(acc, W, cg, H);
-    const uint32_t q = low_bcast(W[0] - (uint32_t)ys[0]);
-    add_q_nr(q, W, cg, U, top, H);
+    uint64_t T[4];
+    uint32_t U[4], top;
+    gather(acc, T, H);
+    const uint32_t q = low_bcast((uint32_t)T[0] - (uint32_t)ys[0]);  // word 0 of the sum has no carry-in
+    add_q_nr(q, T, U, top, H);
     uint32_t bad = (U[0] ^ (uint32_t)ys[0]) | (U[1] ^ (uint32_t)ys[1]) | (U[2] ^ (uint32_t)ys[2]) | (U[3] ^ (uint32_t)ys[3]);
     bad |= (top ^ q) & H.hmask;
     return bad;
 }
 // canonical residue of the digit sums: this half's 4 words in Rw
 HB_DEV void reduce_tile(const v16i& acc, uint32_t (&Rw)[4], const Half& H) {
-    uint32_t W[4], cg, top;
-    gather(acc, W, cg, H);
-    // the high half estimates the quotient from its (un-rippled, so never too large) top 49 bits
-    const uint32_t xq = (cg << 15) | (W[3] >> 17);
+    uint64_t T[4];
+    uint32_t top;
+    gather(acc, T, H);
+    // the high half estimates the quotient from its top word alone: T[3] >> 17 <= (sum >> 241), so never too large
+    const uint32_t xq = (uint32_t)(T[3] >> 17);
     const uint32_t q = high_bcast(__umulhi(xq, Q_RECIP) >> 13);
-    add_q_nr(q, W, cg, Rw, top, H);
+    add_q_nr(q, T, Rw, top, H);
     // exact when word 8 cancels (R = S - q r fits 256 bits) and R's top word is below r's
     const bool fast = H.hmask == 0 || (top == q && Rw[3] < R_TOP);
     if (__builtin_expect(__any(!fast) != 0, 0)) {
         // e = what is left above 2^256 (0 <= e, small); subtract r while e 2^256 + R >= r
         uint32_t e = high_bcast(top - q);
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < 5; ++it) {
             uint32_t D[4];
             uint64_t b = 0;
 #pragma unroll
@@ -169,205 +171,222 @@ HB_DEV void mfma_row(const uint8_t* tab_lane, const v4i (&data)[CG][M], v16i (&a
     }
 }
 
-// Streams one table row (ROWB bytes) from global memory into an LDS buffer with all 256 threads: issue() starts the
-// loads, commit() writes them once the row's MFMAs are done.
-template <int ROWB>
-struct RowStage {
-    static constexpr int PIECES = ROWB / 16;
-    static constexpr int PF = (PIECES + 255) / 256;
-    v4i r[PF];
-    HB_DEV void issue(const uint8_t* __restrict__ src) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int p = (int)threadIdx.x + 256 * k;
-            if (p < PIECES) r[k] = *reinterpret_cast<const v4i*>(src + (size_t)p * 16);
-        }
-    }
-    HB_DEV void commit(uint8_t* dst) const {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int p = (int)threadIdx.x + 256 * k;
-            if (p < PIECES) *reinterpret_cast<v4i*>(dst + (size_t)p * 16) = r[k];
-        }
-    }
+struct MfmaRole {
+    int row0, nrows;  // rows [row0, row0 + nrows) of the table
 };
-
-struct MfmaRecoverArgs {
-    const uint8_t* evals;   // sender rows, canonical 32-byte elements; row s at evals + rows[s] * row_stride * 32
+constexpr int MF_MAX_ROLES = 4;
+struct MfmaRowsArgs {
+    // input: M elements per chunk
+    const uint8_t* in;
     size_t G;
-    size_t row_stride;      // elements
+    int in_chunk_major;   // 1: x[G][M] (encode);  0: sender rows, row s at in + rows[s] * row_stride * 32 (decode)
+    size_t row_stride;    // elements
     RowsArg rows;
-    int needed;             // d + t + 1
-    const uint8_t* table;   // (needed - M) verify rows, then the output rows (M, or 1 for P(0) only)
-    uint32_t* out;          // [G][M] or [G]
-    uint32_t* ncoeffs;
-    uint8_t* status;
+    // table: rows [0, nv) are verify rows (claimed value = sender row M + r), rows >= nv produce output k = r - nv
+    const uint8_t* table;
+    int nv;
+    // output k of chunk g: party-major out + (k * out_stride + g) * 32, or chunk-major out + (g * out_stride + k) * 32
+    uint8_t* out;
+    int out_party_major;
+    size_t out_stride;
+    uint32_t* ncoeffs;    // decode only (nullable): M for accepted chunks
+    uint8_t* status;      // decode only (nullable)
     uint32_t* flagged;
     uint32_t* counters;
-    uint32_t* summary;
+    uint32_t* summary;    // decode only (nullable): initialised by workgroup 0
+    // Roles: the rows of the call cut into groups that fit the LDS.  Workgroups are dealt to roles in blocks of 8
+    // (block j of 8 consecutive workgroups -> role j % nroles) and workgroup b of role k walks the same tile sequence as
+    // workgroup b of every other role: workgroups b and b + 8 sit on the same XCD under round-robin placement, so the
+    // second role to touch a tile finds its input rows in that XCD's L2 (speed only, never correctness).
+    int nroles;
+    int wg_per_role;      // multiple of 8; grid = nroles * wg_per_role
+    MfmaRole role[MF_MAX_ROLES];
+    int abl;              // microbenchmark ablations (tools/ubench_mfma.hip), 0 in the library: 1 = no epilogue arithmetic,
+                          // 2 = no MFMAs, 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored
 };
 
-// One workgroup = 4 waves; a wave owns CG tiles of 32 chunks.
-template <int M, int CG, bool P0_ONLY>
-__global__ __launch_bounds__(256, 2) void k_mfma_recover(MfmaRecoverArgs a) {
-    static_assert(M <= 16, "quotient estimate assumes the sum stays below 2^273");
+template <int M, int CG, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
+    static_assert(M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp) and the sum below 2^273");
     constexpr int ROWB = M * 1024 + 128;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // 2 * ROWB
-    if (blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
+    constexpr int NT = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // role.nrows * ROWB
+    if (a.summary && blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
+    const int blk8 = (int)blockIdx.x >> 3, role_id = blk8 % a.nroles;
+    const int wg_in_role = (blk8 / a.nroles) * 8 + ((int)blockIdx.x & 7);
+    MfmaRole role = a.role[0];
+#pragma unroll
+    for (int k = 1; k < MF_MAX_ROLES; ++k)
+        if (k == role_id) role = a.role[k];
+    {
+        const uint8_t* src = a.table + (size_t)role.row0 * ROWB;
+        const int pieces = role.nrows * (ROWB / 16);
+        for (int p = threadIdx.x; p < pieces; p += NT)
+            *reinterpret_cast<v4i*>(lds + (size_t)p * 16) = *reinterpret_cast<const v4i*>(src + (size_t)p * 16);
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
     const Half H = make_half(h);
-    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * (32 * CG);
-    const int nv = a.needed - M, nrows = nv + (P0_ONLY ? 1 : M);
-    constexpr int OW = P0_ONLY ? 1 : M;
-
-    RowStage<ROWB> stage;
-    stage.issue(a.table);
-    size_t g[CG];
-    bool live[CG];
-    v4i data[CG][M];
+    const size_t ntiles = (a.G + 32 * CG - 1) / (32 * CG);
+    const int nver = role.row0 < a.nv ? (a.nv - role.row0 < role.nrows ? a.nv - role.row0 : role.nrows) : 0;  // verify rows of this role
+    // Addresses are a wave-uniform 64-bit row base plus a 32-bit lane offset (the host keeps G * 32 * max(M, out
+    // width) below 2^32).
+    // HBM latency: a wave that loads the M input rows of its tile and then computes on them for ~20 us leaves too few
+    // bytes in flight per CU (measured: +0.145 ms on config 3 over the same kernel with its inputs in L2,
+    // profiles/r02_ubench_mfma_v3_resident_ablation.txt).  So a wave keeps TWO input register sets and the tile loop is
+    // unrolled by two: at the start of a tile all M loads of its NEXT tile are issued into the other set, a whole tile
+    // ahead of their use.  (Tried and dropped: spreading those loads over the output rows -- register indices that
+    // depend on the row index made hipcc peel the loop and copy the set at every merge; pulling the next tile into L2
+    // with LDS-DMA loads into a scratch slot -- vmcnt is in-order, so the next wait for a claimed value then also waits
+    // for the prefetch issued just before it: 0.44 ms instead of 0.36.)
+    const size_t tstep = (size_t)a.wg_per_role * WAVES;
+    const uint32_t in_lane_stride = a.in_chunk_major ? M * 32u : 32u;
+    auto tile_chunks = [&](size_t t, uint32_t (&gg)[CG]) {
 #pragma unroll
-    for (int cg = 0; cg < CG; ++cg) {
-        const size_t gi = g0 + (size_t)cg * 32 + c;
-        live[cg] = gi < a.G;
-        g[cg] = live[cg] ? gi : a.G - 1;
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-            data[cg][i] = flip(*reinterpret_cast<const v4i*>(a.evals + ((size_t)a.rows[i] * a.row_stride + g[cg]) * 32 + 16 * h));
-    }
-    stage.commit(lds);
-    __syncthreads();
-
-    uint32_t bad[CG];
-#pragma unroll
-    for (int cg = 0; cg < CG; ++cg) bad[cg] = 0;
-    bool okc[CG];
-#pragma unroll
-    for (int cg = 0; cg < CG; ++cg) okc[cg] = true;
-
-    for (int r = 0; r < nrows; ++r) {
-        const uint8_t* cur = lds + (size_t)(r & 1) * ROWB;
-        if (r + 1 < nrows) stage.issue(a.table + (size_t)(r + 1) * ROWB);
-        v4i ys[CG];
-        if (r < nv) {
-#pragma unroll
-            for (int cg = 0; cg < CG; ++cg)
-                ys[cg] = *reinterpret_cast<const v4i*>(a.evals + ((size_t)a.rows[M + r] * a.row_stride + g[cg]) * 32 + 16 * h);
+        for (int cg = 0; cg < CG; ++cg) {
+            const size_t gi = ((a.abl & 4) ? (t & 63) * CG + cg : t * CG + cg) * 32 + c;
+            gg[cg] = (uint32_t)(gi < a.G ? gi : a.G - 1);
         }
-        v16i acc[CG];
-        {
-            const v4i* bp = reinterpret_cast<const v4i*>(cur + M * 1024 + h * 64);
-            const v4i b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-            v16i bias;
+    };
+    auto load_inputs = [&](size_t t, v4i (&dst)[CG][M]) {
+        uint32_t gg[CG];
+        tile_chunks(t, gg);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bias[k] = b0[k], bias[4 + k] = b1[k], bias[8 + k] = b2[k], bias[12 + k] = b3[k];
+        for (int i = 0; i < M; ++i) {
+            const uint8_t* base = a.in_chunk_major ? a.in + (size_t)i * 32 : a.in + (size_t)a.rows[i] * a.row_stride * 32;
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) acc[cg] = bias;
+            for (int cg = 0; cg < CG; ++cg) dst[cg][i] = *reinterpret_cast<const v4i*>(base + (gg[cg] * in_lane_stride + 16u * h));
         }
-        mfma_row<M, CG>(cur + lane * 16, data, acc);
-        if (r < nv) {
+    };
+    // one tile from the register set `data` (raw bytes on entry; sign-flipped in place)
+    auto process_tile = [&](size_t t, v4i (&data)[CG][M]) {
+        uint32_t g[CG];
+        bool live[CG];
+        tile_chunks(t, g);
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) bad[cg] |= verify_tile(acc[cg], ys[cg], H);
-            if (r == nv - 1) {
-                // verdict per chunk: both halves of the lane pair must agree on every verify row
+        for (int cg = 0; cg < CG; ++cg) {
+            live[cg] = (((a.abl & 4) ? (t & 63) * CG + cg : t * CG + cg) * 32 + c) < a.G;
+#pragma unroll
+            for (int i = 0; i < M; ++i) data[cg][i] = flip(data[cg][i]);
+        }
+        auto load_ys = [&](int r, v4i (&ys)[CG]) {  // claimed values of verify row r (table row index)
+            const uint8_t* base = a.in + (size_t)a.rows[M + r] * a.row_stride * 32;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) ys[cg] = *reinterpret_cast<const v4i*>(base + (g[cg] * 32u + 16u * h));
+        };
+        v4i ys_cur[CG], ys_next[CG];
+        if (nver > 0) load_ys(role.row0, ys_cur);
+        uint32_t bad[CG];
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) bad[cg] = 0;
+        for (int r = 0; r < role.nrows; ++r) {
+            const uint8_t* cur = lds + (size_t)r * ROWB;
+            const int rho = role.row0 + r;
+            if (r + 1 < nver) load_ys(rho + 1, ys_next);
+            v16i acc[CG];
+            {
+                const v4i* bp = reinterpret_cast<const v4i*>(cur + M * 1024 + h * 64);
+                const v4i b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+                v16i bias;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bias[k] = b0[k], bias[4 + k] = b1[k], bias[8 + k] = b2[k], bias[12 + k] = b3[k];
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) acc[cg] = bias;
+                if (!(a.abl & 2)) mfma_row<M, CG>(cur + lane * 16, data, acc);
+            }
+            if (a.abl & 1) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) bad[cg] |= (uint32_t)acc[cg][0] & (uint32_t)acc[cg][7] & 0x80000000u;  // digit sums are < 2^24
+            } else if (r < nver) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) bad[cg] |= verify_tile(acc[cg], ys_cur[cg], H) & (a.abl ? 0u : ~0u);
+                if (r + 1 < nver) {
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) ys_cur[cg] = ys_next[cg];
+                }
+            } else {
+                const size_t k = (size_t)(rho - a.nv);
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                    uint32_t Rw[4];
+                    reduce_tile(acc[cg], Rw, H);
+                    uint8_t* qb = a.out_party_major ? a.out + k * a.out_stride * 32 : a.out + k * 32;  // wave-uniform
+                    const uint32_t qo = g[cg] * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
+                    if (live[cg] && (!(a.abl & 4) || Rw[0] == 0x12345u)) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+                }
+            }
+        }
+        // the role that owns the verify rows (all of them: the host never splits them) gives the verdict per chunk;
+        // with no verify rows at all (needed == M) the role of table row 0 accepts every chunk
+        if (a.status != nullptr || a.flagged != nullptr) {
+            if (nver > 0 || (a.nv == 0 && role.row0 == 0)) {
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
                     const unsigned long long m = __ballot(bad[cg] != 0);
                     const uint32_t m32 = (uint32_t)m | (uint32_t)(m >> 32);
-                    okc[cg] = ((m32 >> c) & 1u) == 0;
-                    const bool flag = live[cg] && !okc[cg] && h == 0;
+                    const bool ok = ((m32 >> c) & 1u) == 0;
+                    const bool flag = live[cg] && !ok && h == 0;
                     const unsigned long long fm = __ballot(flag);
                     if (fm != 0) {
                         const int leader = __ffsll((long long)fm) - 1;
                         uint32_t base = 0;
                         if (lane == leader) base = atomicAdd(a.counters, (uint32_t)__popcll(fm));
                         base = __shfl(base, leader);
-                        if (flag) a.flagged[base + __popcll(fm & ((1ull << lane) - 1ull))] = (uint32_t)g[cg];
+                        if (flag) a.flagged[base + __popcll(fm & ((1ull << lane) - 1ull))] = g[cg];
                     }
                     if (live[cg] && h == 0) {
-                        if (a.status) a.status[g[cg]] = okc[cg] ? 0 : 0xff;  // 0xff: pending, rewritten by the fallback kernels
-                        if (a.ncoeffs && okc[cg]) a.ncoeffs[g[cg]] = M;
+                        if (a.status) a.status[g[cg]] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the fallback kernels
+                        if (a.ncoeffs && ok) a.ncoeffs[g[cg]] = M;
                     }
                 }
             }
-        } else {
-            const int k = r - nv;
-#pragma unroll
-            for (int cg = 0; cg < CG; ++cg) {
-                uint32_t Rw[4];
-                reduce_tile(acc[cg], Rw, H);
-                if (live[cg] && okc[cg])
-                    *reinterpret_cast<uint4*>(a.out + ((g[cg] * OW + k) * 8 + 4 * h)) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
-            }
         }
-        if (r + 1 < nrows) stage.commit(lds + (size_t)((r + 1) & 1) * ROWB);
-        __syncthreads();
+    };
+    v4i setA[CG][M], setB[CG][M];
+    size_t t = (size_t)wg_in_role * WAVES + wave;
+    if (t < ntiles) load_inputs(t, setA);
+    const bool pf = !(a.abl & 8);
+    while (t < ntiles) {
+        if (t + tstep < ntiles) load_inputs(t + tstep, setB);
+        process_tile(t, setA);
+        t += tstep;
+        if (t >= ntiles) break;
+        if (t + tstep < ntiles) load_inputs(t + tstep, setA);
+        process_tile(t, setB);
+        t += tstep;
     }
-    if (nv == 0) {
-        // no verify rows (needed == M): every chunk is accepted as it stands
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg)
-            if (live[cg] && h == 0) {
-                if (a.status) a.status[g[cg]] = 0;
-                if (a.ncoeffs) a.ncoeffs[g[cg]] = M;
-            }
-    }
+    (void)pf;
 }
 
-struct MfmaEvalArgs {
-    const uint8_t* x;      // [G][M] chunk-major canonical elements
-    size_t G;
-    const uint8_t* table;  // n output rows
-    int n;
-    uint8_t* y;            // [n][ystride] party-major
-    size_t ystride;        // elements between consecutive output rows
-};
-template <int M, int CG>
-__global__ __launch_bounds__(256, 2) void k_mfma_eval(MfmaEvalArgs a) {
-    static_assert(M <= 16, "quotient estimate assumes the sum stays below 2^273");
-    constexpr int ROWB = M * 1024 + 128;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-    const Half H = make_half(h);
-    const size_t g0 = ((size_t)blockIdx.x * 4 + wave) * (32 * CG);
-    RowStage<ROWB> stage;
-    stage.issue(a.table);
-    size_t g[CG];
-    bool live[CG];
-    v4i data[CG][M];
-#pragma unroll
-    for (int cg = 0; cg < CG; ++cg) {
-        const size_t gi = g0 + (size_t)cg * 32 + c;
-        live[cg] = gi < a.G;
-        g[cg] = live[cg] ? gi : a.G - 1;
-#pragma unroll
-        for (int i = 0; i < M; ++i) data[cg][i] = flip(*reinterpret_cast<const v4i*>(a.x + (g[cg] * M + i) * 32 + 16 * h));
+// Host side: cut `rows` table rows (the first nv of them verify rows, kept together in role 0) into roles of at most
+// `cap` rows, as even as possible, and give every role wg_per_role workgroups (nwg / nroles rounded down to a multiple
+// of 8).  Returns false when the verify rows do not fit one role (the caller then uses the lane-per-chunk kernels).
+inline bool mf_plan_roles(int rows, int nv, int cap, int nwg, MfmaRowsArgs* a) {
+    if (cap < 1 || nv > cap || rows < 1) return false;
+    const int nroles = (rows + cap - 1) / cap;
+    if (nroles > MF_MAX_ROLES) return false;
+    int per = (rows + nroles - 1) / nroles;
+    if (per < nv) per = nv;
+    int r = 0;
+    for (int k = 0; k < nroles; ++k) {
+        int take = k == nroles - 1 ? rows - r : per;
+        if (take > rows - r) take = rows - r;
+        if (take > cap || take < 1) return false;
+        a->role[k].row0 = r;
+        a->role[k].nrows = take;
+        r += take;
     }
-    stage.commit(lds);
-    __syncthreads();
-    for (int r = 0; r < a.n; ++r) {
-        const uint8_t* cur = lds + (size_t)(r & 1) * ROWB;
-        if (r + 1 < a.n) stage.issue(a.table + (size_t)(r + 1) * ROWB);
-        v16i acc[CG];
-        {
-            const v4i* bp = reinterpret_cast<const v4i*>(cur + M * 1024 + h * 64);
-            const v4i b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-            v16i bias;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bias[k] = b0[k], bias[4 + k] = b1[k], bias[8 + k] = b2[k], bias[12 + k] = b3[k];
-#pragma unroll
-            for (int cg = 0; cg < CG; ++cg) acc[cg] = bias;
-        }
-        mfma_row<M, CG>(cur + lane * 16, data, acc);
-#pragma unroll
-        for (int cg = 0; cg < CG; ++cg) {
-            uint32_t Rw[4];
-            reduce_tile(acc[cg], Rw, H);
-            if (live[cg])
-                *reinterpret_cast<uint4*>(a.y + ((size_t)r * a.ystride + g[cg]) * 32 + 16 * h) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
-        }
-        if (r + 1 < a.n) stage.commit(lds + (size_t)((r + 1) & 1) * ROWB);
-        __syncthreads();
-    }
+    if (r != rows) return false;
+    a->nroles = nroles;
+    int w = nwg / nroles / 8 * 8;
+    a->wg_per_role = w < 8 ? 8 : w;
+    return true;
+}
+inline int mf_grid(const MfmaRowsArgs& a) { return a.nroles * a.wg_per_role; }
+inline int mf_max_role_rows(const MfmaRowsArgs& a) {
+    int m = 0;
+    for (int k = 0; k < a.nroles; ++k) m = a.role[k].nrows > m ? a.role[k].nrows : m;
+    return m;
 }
 
 }  // namespace mf

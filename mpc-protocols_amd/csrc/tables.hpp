@@ -184,18 +184,38 @@ inline H horner(const std::vector<H>& p, const H& x) {
 struct RecoverTables {
     std::vector<uint32_t> vm, bc;
 };
-template <class H = HFr>
-inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t, int impl) {
+// the coefficient rows of batch_recover for id-sorted senders (robust_interpolate.rs:343-399, 423):
+//   rows [0, needed - m): verify rows, row s - m = (L_i(x_s))_i for the verify points s = m .. needed-1
+//   rows [needed - m, needed): coefficient rows, row k = (coefficient k of L_i)_i
+template <class H>
+inline std::vector<std::vector<H>> recover_coeff_rows(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t) {
     const size_t m = d + 1, needed = d + t + 1;
     std::vector<H> el = domain_elements<H>(n, n);
     std::vector<H> xs(m);
     for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[i]];
     auto basis = lagrange_basis(xs);
+    std::vector<std::vector<H>> rows;
+    for (size_t s = m; s < needed; ++s) {
+        std::vector<H> row(m);
+        for (size_t i = 0; i < m; ++i) row[i] = horner(basis[i], el[sorted_ids[s]]);
+        rows.push_back(row);
+    }
+    for (size_t k = 0; k < m; ++k) {
+        std::vector<H> row(m);
+        for (size_t i = 0; i < m; ++i) row[i] = basis[i][k];
+        rows.push_back(row);
+    }
+    return rows;
+}
+template <class H = HFr>
+inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t, int impl) {
+    const size_t m = d + 1, needed = d + t + 1;
+    const auto rows = recover_coeff_rows<H>(sorted_ids, n, d, t);
     RecoverTables T;
-    for (size_t s = m; s < needed; ++s)
-        for (size_t i = 0; i < m; ++i) put_const(T.vm, horner(basis[i], el[sorted_ids[s]]), impl);
+    for (size_t r = 0; r < needed - m; ++r)
+        for (size_t i = 0; i < m; ++i) put_const(T.vm, rows[r][i], impl);
     for (size_t k = 0; k < m; ++k)
-        for (size_t i = 0; i < m; ++i) put_const(T.bc, basis[i][k], impl);
+        for (size_t i = 0; i < m; ++i) put_const(T.bc, rows[needed - m + k][i], impl);
     return T;
 }
 

@@ -9,9 +9,11 @@
 // followed by ONE carry pass and one small-quotient reduction per output element.
 //
 // v_mfma_i32_32x32x32_i8 is signed x signed, so the table holds BALANCED digits d in [-128, 127] and the kernel feeds
-// data bytes as s = y - 128 (one XOR per dword); sum y d = sum s d + 128 sum d.  The per-digit constant 128 sum d and a
-// bias that keeps every digit sum non-negative (a multiple of r in total, so it changes nothing mod r) travel as the
-// accumulator's initial value.
+// data bytes as s = y - 128 (one XOR per dword): sum_k y_k T_k = sum_k s_k T_k + 128 sum_k T_k.  The second term is a
+// constant of the row; its residue mod r travels -- as 32 byte digits -- in the accumulator's initial value, together
+// with a bias that keeps every digit sum non-negative (the bias digits sum to a multiple of r, so they change nothing
+// mod r).  Digit sums therefore stay below 32 m * 32768 + 512 < 0xff0000 for m <= 15: two of them combine into one
+// 32-bit value without overflow (v_lshl_add_u32), which halves the 64-bit work of the carry pass.
 //
 // Row layout (one output row = one coefficient row c_0 .. c_{m-1}):  m slabs of 1024 bytes, slab i = the A operand
 // of the MFMA of input i exactly as the 64 lanes hold it (lane (rho, ha): 16 digits, element j <-> data byte
@@ -20,6 +22,7 @@
 // its 16 accumulator registers in order (C/D map of the 32x32 shapes: row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #include <vector>
 
@@ -33,17 +36,71 @@ inline int mf_row_of_digit(int b) {
     const int h = b >> 4, reg = b & 15;
     return (reg & 3) + 8 * (reg >> 2) + 4 * h;
 }
-// per-digit bias magnitude: |sum y d| <= 32 m * 255 * 128 < 32 m * 32768
-inline uint32_t mf_bias_mag(size_t m) { return (uint32_t)(32 * m * 32768); }
+// per-digit bias magnitude: |sum s d| <= 32 m * 128 * 128
+inline uint32_t mf_bias_mag(size_t m) { return (uint32_t)(32 * m * 16384); }
+constexpr size_t MF_MAX_M = 15;  // digit sums < 2 * 32 m * 16384 + 512 must stay below 0xff0000
+
+namespace mfdetail {
+// plain 256-bit integers mod r (canonical, little-endian u64 words): the table needs 32 m shifted copies of every
+// coefficient, and a shift is cheaper as integer arithmetic than as a Montgomery product plus a conversion back
+struct U5 {
+    uint64_t w[5];
+};
+inline bool geq(const U5& a, const U5& b) {
+    for (int i = 4; i >= 0; --i) {
+        if (a.w[i] != b.w[i]) return a.w[i] > b.w[i];
+    }
+    return true;
+}
+inline void sub(U5& a, const U5& b) {
+    unsigned __int128 br = 0;
+    for (int i = 0; i < 5; ++i) {
+        const unsigned __int128 d = (unsigned __int128)a.w[i] - b.w[i] - br;
+        a.w[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+    }
+}
+inline U5 modulus() { return U5{{HFr::MOD[0], HFr::MOD[1], HFr::MOD[2], HFr::MOD[3], 0}}; }
+inline void mul256(uint64_t c[4]) {  // c <- 256 c mod r
+    U5 x{{c[0] << 8, (c[1] << 8) | (c[0] >> 56), (c[2] << 8) | (c[1] >> 56), (c[3] << 8) | (c[2] >> 56), c[3] >> 56}};
+    // quotient estimate from the top 72 bits: q <= floor(x / r) <= q + 1
+    const unsigned __int128 top = ((unsigned __int128)x.w[4] << 64) | x.w[3];
+    const uint64_t q = (uint64_t)(top / ((unsigned __int128)HFr::MOD[3] + 1));
+    unsigned __int128 mc = 0, br = 0;
+    for (int i = 0; i < 5; ++i) {  // x -= q r
+        mc += (unsigned __int128)q * (i < 4 ? HFr::MOD[i] : 0);
+        const unsigned __int128 d = (unsigned __int128)x.w[i] - (uint64_t)mc - br;
+        x.w[i] = (uint64_t)d;
+        br = (d >> 64) & 1;
+        mc >>= 64;
+    }
+    const U5 r = modulus();
+    while (geq(x, r)) sub(x, r);
+    for (int i = 0; i < 4; ++i) c[i] = x.w[i];
+}
+inline void add_mod(uint64_t a[4], const uint64_t b[4]) {  // a <- a + b mod r (a, b < r)
+    U5 x{{0, 0, 0, 0, 0}};
+    unsigned __int128 cy = 0;
+    for (int i = 0; i < 4; ++i) {
+        cy += (unsigned __int128)a[i] + b[i];
+        x.w[i] = (uint64_t)cy;
+        cy >>= 64;
+    }
+    x.w[4] = (uint64_t)cy;
+    const U5 r = modulus();
+    if (geq(x, r)) sub(x, r);
+    for (int i = 0; i < 4; ++i) a[i] = x.w[i];
+}
+}  // namespace mfdetail
 
 // C: rows x m coefficient matrix.  Returns rows * mf_row_bytes(m) bytes (as u32 words).
 inline std::vector<uint32_t> build_mfma_table(const std::vector<std::vector<HFr>>& C, size_t m) {
     const size_t RB = mf_row_bytes(m);
     std::vector<uint32_t> out(C.size() * RB / 4, 0u);
     uint8_t* base = reinterpret_cast<uint8_t*>(out.data());
-    const HFr s256 = HFr::from_u64(256);
     // E = (Bmag * sum_b 256^b) mod r: the bias digits are Bmag - byte_b(E), which sum to a multiple of r
     const uint32_t bmag = mf_bias_mag(m);
+    const HFr s256 = HFr::from_u64(256);
     HFr acc = HFr::zero(), p = HFr::one();
     for (int b = 0; b < 32; ++b) {
         acc = acc + p;
@@ -54,30 +111,42 @@ inline std::vector<uint32_t> build_mfma_table(const std::vector<std::vector<HFr>
     acc.to_canon(e);
     for (size_t r = 0; r < C.size(); ++r) {
         uint8_t* row = base + r * RB;
-        int64_t dsum[32] = {0};
+        uint64_t tsum[4] = {0, 0, 0, 0};  // sum_k T_k mod r
         for (size_t i = 0; i < m; ++i) {
             int8_t* tile = reinterpret_cast<int8_t*>(row + i * 1024);
-            HFr v = C[r][i];
+            uint64_t c[4];
+            C[r][i].to_canon(c);
+            // balanced digits of x = the bytes of x + 0x80..80 (carries propagate), each minus 128: one 256-bit add
+            // and one XOR per shifted copy.  (The top byte of a canonical value is <= 0x73: no carry out.)
+            int8_t D[32][32];  // D[a][b] = digit b of c * 2^(8a) mod r
             for (int a = 0; a < 32; ++a) {
-                uint64_t c[4];
-                v.to_canon(c);
-                int carry = 0;
-                for (int b = 0; b < 32; ++b) {
-                    int x = (int)((c[b >> 3] >> (8 * (b & 7))) & 0xff) + carry;
-                    carry = x >= 128;
-                    if (carry) x -= 256;
-                    const int lane = mf_row_of_digit(b) + 32 * (a >> 4);
-                    tile[lane * 16 + (a & 15)] = (int8_t)x;
-                    dsum[b] += x;
+                mfdetail::add_mod(tsum, c);
+                uint64_t y[4];
+                unsigned __int128 cy = 0;
+                for (int w = 0; w < 4; ++w) {
+                    cy += (unsigned __int128)c[w] + 0x8080808080808080ULL;
+                    y[w] = (uint64_t)cy ^ 0x8080808080808080ULL;
+                    cy >>= 64;
                 }
-                // the top byte of a canonical value is <= 0x73: the last digit never carries out
-                v = v * s256;
+                memcpy(D[a], y, 32);
+                mfdetail::mul256(c);
             }
+            for (int b = 0; b < 32; ++b)
+                for (int ha = 0; ha < 2; ++ha) {
+                    int8_t* dst = tile + (mf_row_of_digit(b) + 32 * ha) * 16;
+                    for (int j = 0; j < 16; ++j) dst[j] = D[16 * ha + j][b];
+                }
+        }
+        uint64_t cr[4] = {tsum[0], tsum[1], tsum[2], tsum[3]};  // 128 * sum_k T_k mod r
+        for (int k = 0; k < 7; ++k) {
+            uint64_t dbl[4] = {cr[0], cr[1], cr[2], cr[3]};
+            mfdetail::add_mod(cr, dbl);
         }
         int32_t* bias = reinterpret_cast<int32_t*>(row + m * 1024);
         for (int b = 0; b < 32; ++b) {
             const int32_t eb = (int32_t)((e[b >> 3] >> (8 * (b & 7))) & 0xff);
-            bias[b] = (int32_t)(128 * dsum[b]) + (int32_t)bmag - eb;
+            const int32_t cb = (int32_t)((cr[b >> 3] >> (8 * (b & 7))) & 0xff);
+            bias[b] = (int32_t)bmag - eb + cb;
         }
     }
     return out;

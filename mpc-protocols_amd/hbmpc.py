@@ -113,6 +113,13 @@ class Engine:
     def set_small_batch_chunks(self, max_chunks: int):
         assert self.L.hbmpc_set_small_batch_chunks(self.ctx, C.c_size_t(max_chunks)) == 0
 
+    def set_matrix_cores(self, on: bool, min_chunks: int = 0):
+        """large Fr decodes on the matrix cores (int8 MFMA); min_chunks = 0 keeps the current threshold"""
+        assert self.L.hbmpc_set_matrix_cores(self.ctx, C.c_int(1 if on else 0), C.c_size_t(min_chunks)) == 0
+
+    def set_matrix_core_workgroups(self, workgroups: int):
+        assert self.L.hbmpc_set_matrix_core_workgroups(self.ctx, C.c_int(workgroups)) == 0
+
     def set_second_chance(self, on: bool):
         assert self.L.hbmpc_set_second_chance(self.ctx, C.c_int(1 if on else 0)) == 0
 

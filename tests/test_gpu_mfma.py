@@ -1,0 +1,156 @@
+"""The matrix-core (int8 MFMA) decode, csrc/kernels_mfma.hpp, against the oracle and against the lane-per-chunk
+kernels: every d + 1 it instantiates, role splits, ragged tails, the multi-tile loop of a wave (few workgroups),
+corruption inside and outside the interpolation set, arrival orders, missing senders, P(0)-only, strided rows, and
+BASELINE configs[2] at full size.  Bar: bit-exact."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import cref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = load_package().Engine(0)
+    e.set_small_batch_chunks(0)
+    yield e
+    e.close()
+
+
+def rnd(seed, *shape):
+    return O.fill_random(seed, int(np.prod(shape))).reshape(*shape, 4)
+
+
+def codewords(seed, G, n, d):
+    x = rnd(seed, G, d + 1)
+    x[0] = 0                                   # the zero polynomial
+    x[1 % G, :, :] = 0
+    x[1 % G, 0, 0] = 1                         # the constant 1
+    if G > 2:
+        x[2, :] = O.ints_to_u256([O_R - 1] * (d + 1))   # every coefficient r - 1
+    rc, y = O.vandermonde_apply(x, n, d)
+    assert rc == 0
+    return x, y
+
+
+O_R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+def both_ways(eng, ids, ev, n, d, t, p0=False):
+    """the same call through the matrix-core kernels and through the lane-per-chunk kernels"""
+    call = eng.batch_recover_p0 if p0 else eng.batch_recover
+    eng.set_matrix_cores(True, 1)
+    a = call(ids, ev, n, d, t)
+    eng.set_matrix_cores(False)
+    b = call(ids, ev, n, d, t)
+    eng.set_matrix_cores(True, 65536)
+    return a, b
+
+
+SHAPES = [  # (n, d, t): d + 1 = 2 .. 15, verify rows 0 .. 10; (16, 10, 5) is config 4's decode, (31, 10, 10) config 3's
+    (4, 1, 1), (7, 2, 2), (10, 3, 3), (13, 4, 4), (16, 5, 5), (19, 6, 6), (22, 7, 7), (25, 8, 8), (28, 9, 9),
+    (31, 10, 10), (16, 10, 5), (34, 11, 11), (37, 12, 12), (40, 13, 13), (43, 14, 13), (16, 14, 0), (31, 4, 10),
+    (5, 1, 1), (10, 3, 2), (20, 6, 6),
+]
+
+
+@pytest.mark.parametrize("n,d,t", SHAPES)
+@pytest.mark.parametrize("wgs", [0, 8])
+def test_shapes_vs_oracle(eng, n, d, t, wgs):
+    G = 1500 + 37 if wgs == 0 else 9000 + 5   # wgs = 8: every wave walks several tiles (both input register sets)
+    eng.set_matrix_core_workgroups(wgs)
+    try:
+        x, y = codewords(100 + n + d, G, n, d)
+        rng = np.random.default_rng(n * 1000 + d)
+        # corruption: a verify row (if any), an interpolation row, two rows at once, and a chunk beyond repair
+        y[min(d + 1, n - 1), 5, 0] ^= 1
+        y[0, 6, 3] ^= 1 << 40
+        y[1, 7, 1] ^= 7
+        y[min(d + 2, n - 1), 7, 2] ^= 9
+        for j in rng.choice(n, size=min(n, 2 * t + 2), replace=False):
+            y[j, 8, 0] ^= 0x55
+        ids = list(range(n))
+        (rc, co, nco, st), lane = both_ways(eng, ids, y, n, d, t)
+        rc0, co0, nco0, st0 = O.batch_recover(ids, y, n, d, t)
+        assert rc == rc0 and np.array_equal(st, st0) and np.array_equal(nco, nco0) and np.array_equal(co, co0)
+        assert lane[0] == rc and all(np.array_equal(u, v) for u, v in zip(lane[1:], (co, nco, st)))
+        ok = st0 == 0
+        ok[5:9] = False                        # t = 0 has no verify rows: a corrupted chunk is accepted as another polynomial
+        assert ok.sum() >= G - 4 and np.array_equal(co[ok], x[ok])
+        (rc, p0, st), lane = both_ways(eng, ids, y, n, d, t, p0=True)
+        assert rc == rc0 and np.array_equal(st, st0) and np.array_equal(p0, co0[:, 0])
+        assert lane[0] == rc and np.array_equal(lane[1], p0) and np.array_equal(lane[2], st)
+    finally:
+        eng.set_matrix_core_workgroups(0)
+
+
+@pytest.mark.parametrize("n,d,t", [(31, 10, 10), (16, 5, 5), (16, 10, 5)])
+def test_arrival_orders_and_missing_senders(eng, n, d, t):
+    G = 3000 + 11
+    x, y = codewords(7 + n, G, n, d)
+    rng = np.random.default_rng(n + d)
+    for trial in range(4):
+        S = n if trial == 0 else int(rng.integers(d + t + 1, n + 1))
+        ids = [int(i) for i in rng.permutation(n)[:S]]
+        ev = np.ascontiguousarray(y[ids])
+        bad = rng.choice(G, size=20, replace=False)
+        ev[int(rng.integers(0, S)), bad, 0] ^= 1     # one lying sender in 20 chunks
+        (rc, co, nco, st), lane = both_ways(eng, ids, ev, n, d, t)
+        rc0, co0, nco0, st0 = O.batch_recover(ids, ev, n, d, t)
+        assert rc == rc0 and np.array_equal(st, st0) and np.array_equal(nco, nco0) and np.array_equal(co, co0)
+        assert lane[0] == rc and all(np.array_equal(u, v) for u, v in zip(lane[1:], (co, nco, st)))
+
+
+def test_full_size_config3(eng):
+    """BASELINE configs[2]: n = 31, t = 10, 2^20 chunks through the device API; whole-array equality with the
+    lane-per-chunk kernels, a sampled comparison with the oracle, and the round trip."""
+    import torch
+    n, t, d, G = 31, 10, 10, 1 << 20
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC0FFEE02)
+    lo = torch.randint(0, 1 << 62, (G, d + 1, 3), dtype=torch.int64, device=dev, generator=gen)
+    hi = torch.randint(0, 0x73EDA753299D7D48, (G, d + 1, 1), dtype=torch.int64, device=dev, generator=gen)
+    x = torch.cat([lo, hi], dim=-1).contiguous()
+    y = torch.empty((n, G, 4), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), 0) == 0
+    eng.sync()
+    # corrupt: the t lowest senders in 1 % of the chunks, plus a verify-row lie and an unrepairable chunk
+    bad = torch.randperm(G, device=dev, generator=gen)[: G // 100]
+    y[:t, bad, 0] ^= 1
+    y[15, 12345, 2] ^= 1 << 33
+    y[:, 777, 1] ^= 3
+    ids = list(range(n))
+    outs = {}
+    for mode in ("mfma", "lane"):
+        eng.set_matrix_cores(mode == "mfma", 65536)
+        co = torch.full((G, d + 1, 4), -1, dtype=torch.int64, device=dev)
+        nco = torch.zeros((G,), dtype=torch.int32, device=dev)
+        st = torch.zeros((G,), dtype=torch.uint8, device=dev)
+        summ = torch.zeros((4,), dtype=torch.int32, device=dev)
+        sec = torch.full((G, 4), -1, dtype=torch.int64, device=dev)
+        st2 = torch.zeros((G,), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        assert eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, co.data_ptr(), nco.data_ptr(), st.data_ptr(), summ.data_ptr(), 0) == 0
+        assert eng.dev_batch_recover(ids, y.data_ptr(), G, n, d, t, sec.data_ptr(), 0, st2.data_ptr(), 0, 0, p0=True) == 0
+        eng.sync()
+        outs[mode] = (co, nco, st, summ, sec, st2)
+    eng.set_matrix_cores(True, 65536)
+    for u, v in zip(outs["mfma"], outs["lane"]):
+        assert torch.equal(u, v)
+    co, nco, st, summ, sec, st2 = outs["mfma"]
+    sm = summ.cpu().numpy().view(np.uint32)
+    assert int(sm[0]) == G // 100 + 2 - int((bad == 12345).sum()) - int((bad == 777).sum()) and int(sm[1]) == 1 and int(sm[2]) == 777
+    good = st <= 1
+    assert int(good.sum()) == G - 1 and torch.equal(co[good], x[good]) and torch.equal(sec[good], x[good][:, 0])
+    # sampled chunks against the oracle: first, last, tile and workgroup boundaries, the corrupted ones
+    idx = np.unique(np.concatenate([np.arange(0, 70), np.arange(G - 70, G), np.arange(31, G, 32)[:50], np.arange(32 * 3072 - 3, 32 * 3072 + 3),
+                                    bad.cpu().numpy()[:300], [12345, 777]]))
+    ys = y[:, torch.as_tensor(idx, device=dev)].cpu().numpy().view(np.uint64)
+    rc0, co0, nco0, st0 = O.batch_recover(ids, np.ascontiguousarray(ys), n, d, t)
+    ti = torch.as_tensor(idx, device=dev)
+    assert np.array_equal(co[ti].cpu().numpy().view(np.uint64), co0) and np.array_equal(st[ti].cpu().numpy(), st0)
+    assert np.array_equal(nco[ti].cpu().numpy().view(np.uint32), nco0)

@@ -22,18 +22,21 @@ def eng():
     e.close()
 
 
-@pytest.fixture(params=["u29", "u29-lane", "u29-generic", "sat32", "sat32-lane"])
+@pytest.fixture(params=["u29", "u29-lane", "u29-mfma", "u29-mfma-gao", "u29-generic", "sat32", "sat32-lane"])
 def eng_all(request, eng):
     """u29 / sat32: the defaults (small batches decode with the wave-per-chunk kernel); -lane: the lane-per-chunk
-    kernels the large batches use, at every size; -generic: the runtime-shaped kernels"""
+    kernels at every size; -mfma: the matrix-core decode the large batches use, at every size (the second: every flagged
+    chunk to OEC/Gao); -generic: the runtime-shaped kernels"""
     mode = request.param
     eng.set_impl("sat32" if mode.startswith("sat32") else "u29")
     eng.set_force_generic(mode == "u29-generic")
-    eng.set_small_batch_chunks(0 if mode.endswith("-lane") else 8192)
+    eng.set_small_batch_chunks(0 if mode.endswith("-lane") or "-mfma" in mode else 8192)
+    eng.set_matrix_cores("-mfma" in mode, 1 if "-mfma" in mode else 65536)
     # the defaults resolve most flagged chunks in the second-chance kernel; the other modes send every flagged chunk
     # to the OEC/Gao kernel, so both fallbacks see every corruption case of this file
-    eng.set_second_chance(mode in ("u29", "sat32"))
+    eng.set_second_chance(mode in ("u29", "sat32", "u29-mfma"))
     yield eng
+    eng.set_matrix_cores(True, 65536)
     eng.set_impl("u29")
     eng.set_force_generic(False)
     eng.set_small_batch_chunks(8192)

@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "hbmpc" not in k:
+        if "hbmpc" not in k and "mfma" not in k:
             continue
         agg[k.split("(")[0][-60:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():

@@ -2,7 +2,7 @@
 // (VERDICT r1 item 2): runs csrc/kernels_mfma.hpp at the BASELINE shapes on random data, checks sampled chunks against
 // host field arithmetic (HFr), and prints ms per launch.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_mfma.hip -o tools/ubench_mfma
-//   tools/ubench_mfma [log2_chunks=20] [reps=20]
+//   tools/ubench_mfma [log2_chunks=20] [reps=20] [shape mask=127] [workgroups=256]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,19 +52,26 @@ static float time_ms(F f, int reps) {
     return ms / reps;
 }
 
-template <int M, int CG>
-static void launch_eval(const mf::MfmaEvalArgs& a) {
-    const size_t per = 128 * CG;
-    hipLaunchKernelGGL((mf::k_mfma_eval<M, CG>), dim3((unsigned)((a.G + per - 1) / per)), dim3(256), 2 * (M * 1024 + 128), 0, a);
-}
-template <int M, int CG, bool P0>
-static void launch_rec(const mf::MfmaRecoverArgs& a) {
-    const size_t per = 128 * CG;
-    hipLaunchKernelGGL((mf::k_mfma_recover<M, CG, P0>), dim3((unsigned)((a.G + per - 1) / per)), dim3(256), 2 * (M * 1024 + 128), 0, a);
+static int g_nwg = 256;  // workgroups per launch (one per CU: the table rows of a role fill most of the LDS)
+template <int M, int CG, int WAVES>
+static void launch_rows(mf::MfmaRowsArgs a, int rows) {
+    constexpr int ROWB = M * 1024 + 128;
+    const int cap = (160 * 1024) / ROWB;
+    if (!mf::mf_plan_roles(rows, a.nv, cap, g_nwg, &a)) {
+        fprintf(stderr, "rows do not fit the role plan\n");
+        exit(2);
+    }
+    const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 // encode x[G][M] with [I ; Cv] -> evals[M + nv][G]; decode with verify rows Cv and output rows Co; check vs host
-template <int M, int CG>
+template <int M, int CG, int WAVES>
 static int run_shape(const char* name, int nv, size_t G, int reps) {
     std::vector<std::vector<HFr>> Cv(nv, std::vector<HFr>(M)), Co(M, std::vector<HFr>(M)), Cenc;
     for (auto& row : Cv)
@@ -112,8 +119,9 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
     CK(hipMalloc(&d_sum, 16));
     CK(hipMemcpy(d_x, x.data(), G * M * 32, hipMemcpyHostToDevice));
     CK(hipMemset(d_cnt, 0, 16));
-    mf::MfmaEvalArgs ea = {d_x, G, d_tenc, n, d_y, G};
-    launch_eval<M, CG>(ea);
+    mf::MfmaRowsArgs ea = {};
+    ea.in = d_x, ea.G = G, ea.in_chunk_major = 1, ea.table = d_tenc, ea.nv = 0, ea.out = d_y, ea.out_party_major = 1, ea.out_stride = G;
+    launch_rows<M, CG, WAVES>(ea, n);
     CK(hipDeviceSynchronize());
     int errors = 0;
     // sample chunks
@@ -147,12 +155,12 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
         v[3] ^= 1ull << 40;
         CK(hipMemcpy(d_y + ((size_t)2 * G + bad2) * 32, v, 32, hipMemcpyHostToDevice));
     }
-    mf::MfmaRecoverArgs ra = {};
-    ra.evals = d_y, ra.G = G, ra.row_stride = G, ra.needed = n, ra.table = d_tdec, ra.out = (uint32_t*)d_out;
+    mf::MfmaRowsArgs ra = {};
+    ra.in = d_y, ra.G = G, ra.in_chunk_major = 0, ra.row_stride = G, ra.table = d_tdec, ra.nv = nv, ra.out = d_out, ra.out_party_major = 0, ra.out_stride = M;
     ra.status = d_st, ra.flagged = d_flag, ra.counters = d_cnt, ra.summary = d_sum;
     for (int s = 0; s < n; ++s) ra.rows.set(s, s);
     CK(hipMemset(d_out, 0xEE, G * M * 32));
-    launch_rec<M, CG, false>(ra);
+    launch_rows<M, CG, WAVES>(ra, nv + M);
     CK(hipDeviceSynchronize());
     uint32_t cnt[4];
     CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
@@ -180,24 +188,34 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
         }
     }
     // restore the corrupted values so the timed decode takes the optimistic path everywhere
-    launch_eval<M, CG>(ea);
+    launch_rows<M, CG, WAVES>(ea, n);
     CK(hipMemset(d_cnt, 0, 16));
     CK(hipDeviceSynchronize());
-    const float ms_enc = time_ms([&] { launch_eval<M, CG>(ea); }, reps);
-    const float ms_dec = time_ms([&] { launch_rec<M, CG, false>(ra); }, reps);
-    mf::MfmaRecoverArgs rp = ra;
-    rp.table = d_tp0;
-    const float ms_p0 = time_ms([&] { launch_rec<M, CG, true>(rp); }, reps);
+    const float ms_enc = time_ms([&] { launch_rows<M, CG, WAVES>(ea, n); }, reps);
+    const float ms_dec = time_ms([&] { launch_rows<M, CG, WAVES>(ra, nv + M); }, reps);
+    mf::MfmaRowsArgs rp = ra;
+    rp.table = d_tp0, rp.out_stride = 1;
+    const float ms_p0 = time_ms([&] { launch_rows<M, CG, WAVES>(rp, nv + 1); }, reps);
     CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+    if (G > 100000) {
+        fprintf(stderr, "   ablation %s CG=%d waves=%d: full %.4f ms", name, CG, WAVES, ms_dec);
+        for (int abl : {1, 2, 4, 5, 6, 7}) {
+            mf::MfmaRowsArgs rb = ra;
+            rb.abl = abl;
+            fprintf(stderr, " | abl %d: %.4f", abl, time_ms([&] { launch_rows<M, CG, WAVES>(rb, nv + M); }, reps));
+        }
+        fprintf(stderr, "   (1 = no epilogue, 2 = no MFMA, 4 = inputs from L2 + no stores)\n");
+        CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+    }
     if (cnt[0] != 0) {
         fprintf(stderr, "%s: %u chunks flagged in the clean timed runs\n", name, cnt[0]);
         ++errors;
     }
     const double enc_b = (double)(M + n) * 32 * G, dec_b = (double)(n + M) * 32 * G, p0_b = (double)(n + 1) * 32 * G;
-    printf("{\"shape\": \"%s\", \"M\": %d, \"rows_verify\": %d, \"CG\": %d, \"chunks\": %zu, \"errors\": %d, "
+    printf("{\"shape\": \"%s\", \"M\": %d, \"rows_verify\": %d, \"CG\": %d, \"waves\": %d, \"chunks\": %zu, \"errors\": %d, "
            "\"encode_%d_rows_ms\": %.4f, \"encode_GBps\": %.0f, \"decode_ms\": %.4f, \"decode_GBps\": %.0f, "
            "\"decode_p0_ms\": %.4f, \"decode_p0_GBps\": %.0f}\n",
-           name, M, nv, CG, G, errors, n, ms_enc, enc_b / ms_enc / 1e6, ms_dec, dec_b / ms_dec / 1e6, ms_p0, p0_b / ms_p0 / 1e6);
+           name, M, nv, CG, WAVES, G, errors, n, ms_enc, enc_b / ms_enc / 1e6, ms_dec, dec_b / ms_dec / 1e6, ms_p0, p0_b / ms_p0 / 1e6);
     fflush(stdout);
     for (void* q : {(void*)d_tenc, (void*)d_tdec, (void*)d_tp0, (void*)d_x, (void*)d_y, (void*)d_out, (void*)d_st, (void*)d_flag, (void*)d_cnt, (void*)d_sum}) (void)hipFree(q);
     return errors;
@@ -208,12 +226,17 @@ int main(int argc, char** argv) {
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
     const size_t G = (size_t)1 << lg;
     int errors = 0;
+    const int mask = argc > 3 ? atoi(argv[3]) : 0x7f;
     // ragged small case first (live masks, partial tiles)
-    errors += run_shape<11, 2>("cfg3_ragged", 10, 1000 + 37, 2);
-    errors += run_shape<11, 1>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
-    errors += run_shape<11, 2>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
-    errors += run_shape<6, 2>("cfg2-like m=6, 10 extra rows", 10, G, reps);
-    errors += run_shape<6, 4>("cfg2-like m=6, 10 extra rows", 10, G, reps);
+    if (argc > 4) g_nwg = atoi(argv[4]);
+    if (mask & 1) errors += run_shape<11, 2, 8>("cfg3_ragged", 10, 1000 + 37, 2);
+    if (mask & 1) errors += run_shape<11, 1, 16>("cfg3_ragged", 10, 3000 + 5, 2);
+    if (mask & 2) errors += run_shape<11, 1, 8>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    if (mask & 4) errors += run_shape<11, 1, 12>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    if (mask & 8) errors += run_shape<11, 1, 16>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    if (mask & 16) errors += run_shape<11, 2, 8>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    if (mask & 32) errors += run_shape<6, 1, 16>("cfg2-like m=6, 10 extra rows", 10, G, reps);
+    if (mask & 64) errors += run_shape<6, 2, 8>("cfg2-like m=6, 10 extra rows", 10, G, reps);
     fprintf(stderr, errors ? "FAILED: %d errors\n" : "all checks passed\n", errors);
     return errors != 0;
 }
