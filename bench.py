@@ -36,22 +36,41 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn):
-    """W untimed warmups, then EXACTLY K steps bracketed by barrier+sync; returns max-over-ranks seconds."""
+def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prewarm_s=0.0, events=None):
+    """Untimed pre-warm by TIME (launch until prewarm_s seconds have passed: the chip's clocks and caches need a few
+    hundred ms of load to settle, which a count of W short launches does not cover), then W untimed warmups, then
+    EXACTLY K steps bracketed by barrier+sync.  `events` = (ev0, ev1, record) brackets the SAME K launches with two HIP
+    events on the launch stream: kernel_ms comes from the timed region itself.  Returns a dict; "secs" is the
+    max-over-ranks wall time of the K steps."""
+    t_pre = time.perf_counter()
+    pre_steps = 0
+    while prewarm_s > 0 and time.perf_counter() - t_pre < prewarm_s:
+        for _ in range(32):
+            step_fn()
+        pre_steps += 32
+        sync_fn()
+    prewarm_ms = (time.perf_counter() - t_pre) * 1e3 if prewarm_s > 0 else 0.0
     for _ in range(warmup):
         step_fn()
     sync_fn()
     barrier_fn()
+    if events:
+        events[2](events[0])
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+    if events:
+        events[2](events[1])
     sync_fn()
     dt = time.perf_counter() - t0
     barrier_fn()
-    return max_reduce_fn(dt)
+    out = {"secs": max_reduce_fn(dt), "prewarm_ms": prewarm_ms, "prewarm_steps": pre_steps}
+    if events:
+        out["kernel_ms"] = events[0].elapsed_time(events[1]) / steps
+    return out
 
 
-def cpu_baseline(n, d, sample, check=None):
+def cpu_baseline(n, d, sample, check=None, min_seconds=10.0):
     """The only place bench.py touches oracle/: the CPU restatement timed as the reported baseline ("port"), and --
     as the checker it is -- compared once with the benchmarked GPU buffers (check = (coeffs, shares) of the first
     secrets of the timed batch, copied to the host)."""
@@ -64,7 +83,7 @@ def cpu_baseline(n, d, sample, check=None):
     # a bounded sample of the same workload: repeat the pass over `sample` secrets until >= 10 s of CPU work
     reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    while reps < 16 and dt < 10.0:
+    while reps < 16 and dt < min_seconds:
         rc, _ = cref.compute_shares(x, n, d)
         assert rc == 0
         reps += 1
@@ -74,21 +93,62 @@ def cpu_baseline(n, d, sample, check=None):
                       f"{os.path.basename(cref.build())}", "seconds": round(dt, 2)}
 
 
-def cpu_baseline_threads(n, d, sample):
+def cpu_baseline_recon(n, d, t, sample, check=None, min_seconds=5.0):
+    """The recon half of the metric on one host thread: the restatement of batch_recover_secret (shared Lagrange basis,
+    per-chunk verify + recover, robust_interpolate.rs:284-443) on valid codewords.  check = (evals, coeffs) of the first
+    chunks of the benchmarked decode."""
+    from oracle import cref
+    ids = list(range(n))
+    if check is not None:
+        rc, want, _, st = cref.batch_recover(ids, np.ascontiguousarray(check[0]), n, d, t)
+        assert rc == 0 and not st.any() and np.array_equal(check[1], want), "bench decode differs from the oracle"
+    x = cref.fill_random(0xC0FFEE02, sample * (d + 1)).reshape(sample, d + 1, 4)
+    rc, y = cref.vandermonde_apply(x, n, d)
+    assert rc == 0
+    reps, dt = 0, 0.0
+    t0 = time.perf_counter()
+    while reps < 64 and dt < min_seconds:
+        rc, co, _, st = cref.batch_recover(ids, y, n, d, t)
+        assert rc == 0
+        reps += 1
+        dt = time.perf_counter() - t0
+    assert np.array_equal(co, x)
+    return {"value": sample * reps / dt, "unit": "recons/s", "cores": 1, "kind": "port",
+            "sample": f"batch_recover n={n} d={d} t={t}: {reps} passes over {sample} chunks of valid codewords, single thread",
+            "seconds": round(dt, 2)}
+
+
+def cpu_baseline_threads(n, d, sample, min_seconds=2.0):
     """the same restatement on every host core (the reference itself is single-threaded on this path; SURVEY 8(d)
-    asks for both).  ctypes releases the GIL during the C call."""
+    asks for both).  ctypes releases the GIL during the C call; every thread repeats its pass until >= 2 s."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import cref
     cores = len(os.sched_getaffinity(0))
-    per = sample // cores
+    per = max(1024, sample // cores)
     xs = [cref.fill_random(0xC0FFEE10 + i, per * (d + 1)).reshape(per, d + 1, 4) for i in range(cores)]
+
+    def work(x):
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min_seconds:
+            assert cref.compute_shares(x, n, d)[0] == 0
+            reps += 1
+        return reps
+
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        rcs = list(ex.map(lambda x: cref.compute_shares(x, n, d)[0], xs))
+        reps = list(ex.map(work, xs))
         dt = time.perf_counter() - t0
-    assert not any(rcs)
-    return {"value": n * per * cores / dt, "unit": "shares/s", "cores": cores, "kind": "port",
-            "sample": f"compute_shares n={n} d={d} on {per} secrets per thread", "seconds": round(dt, 2)}
+    return {"value": n * per * sum(reps) / dt, "unit": "shares/s", "cores": cores, "kind": "port",
+            "sample": f"compute_shares n={n} d={d}: {per} secrets per thread, {min(reps)}..{max(reps)} passes each",
+            "seconds": round(dt, 2)}
+
+
+def traffic_record(key):
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tr)).get(key)
+    except Exception:
+        return None
 
 
 def main():
@@ -98,11 +158,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--log2-batch", type=int, default=20)
     ap.add_argument("--cpu-sample-log2", type=int, default=22)
+    ap.add_argument("--prewarm-seconds", type=float, default=0.5,
+                    help="untimed launches of the same step until this much wall time has passed (before the W warmups)")
+    ap.add_argument("--workload", default="cfg2+cfg3", choices=["cfg2+cfg3", "cfg4", "cfg5"],
+                    help="cfg2+cfg3 (default): the two halves of BASELINE.json's metric, 2^20 secrets / chunks per GPU "
+                         "(weak scaling).  cfg4 / cfg5: the triple_gen / fpmul pipelines of BASELINE configs[3] / [4], their "
+                         "fixed batch sharded over the ranks (strong scaling)")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--final-gather", action="store_true",
-                    help="N > 1: after the timed region, all-gather the shares of all ranks once (the path's only "
-                         "collective, optional for consumers that read per-device slices) and report its time")
+    ap.add_argument("--no-final-gather", action="store_true",
+                    help="N > 1: skip the all-gather of the shares after the timed region (the path's only collective)")
     ap.add_argument("--impl", default="u29", choices=["u29", "sat32"])
+    ap.add_argument("--recon-kernels", default="mfma", choices=["mfma", "lane"],
+                    help="batch_recover on the matrix cores (default) or with the lane-per-chunk kernels (A/B)")
     args = ap.parse_args()
 
     import torch
@@ -124,24 +191,15 @@ def main():
     from __graft_entry__ import load_package
     pkg = load_package()
     eng = pkg.Engine(local_rank, impl=args.impl)
+    eng.set_matrix_cores(args.recon_kernels == "mfma")
 
-    n, t, d = 16, 5, 5
-    B = 1 << args.log2_batch  # per GPU (weak scaling)
-    torch.manual_seed(0xC0FFEE01 + rank)  # synthetic inputs: canonical, uniform-ish field elements drawn on the device
-    coeffs = _rand_fr(torch, dev, B, d + 1)                         # [B][d+1][4] resident in HBM (this rank's shard)
-    shares = torch.empty((n, B, 4), dtype=torch.int64, device=dev)  # [n][B][4]
     # an explicit (non-default) torch stream: its handle goes through the C ABI, so the kernels, the
-    # torch.cuda.Event timings and the copies above are all ordered on ONE stream
+    # torch.cuda.Event timings and the copies are all ordered on ONE stream
     tstream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-
-    def step():
-        rc = eng.dev_compute_shares(coeffs.data_ptr(), B, n, d, shares.data_ptr(), stream)
-        if rc != 0:
-            raise RuntimeError(f"hbmpc_dev_compute_shares -> {rc}: {eng.last_error()}")
 
     def barrier():
         if world > 1:
@@ -154,65 +212,73 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def events():
+        return (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), lambda e: e.record())
+
+    ctx = dict(args=args, torch=torch, dist=dist, dev=dev, eng=eng, stream=stream, rank=rank, world=world,
+               barrier=barrier, max_reduce=max_reduce, events=events)
+    if args.workload == "cfg2+cfg3":
+        out = bench_metric(ctx)
+    else:
+        out = bench_pipeline(ctx)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_metric(ctx):
+    """BASELINE.json's metric: shares/s of compute_shares (configs[1]) -- `value` -- and recons/s of batch_recon
+    (configs[2]) -- `recon` --, both on this rank's 2^20-element shard, timed with the same barrier / max-over-ranks
+    contract."""
+    args, torch, dist, dev, eng, stream = (ctx[k] for k in ("args", "torch", "dist", "dev", "eng", "stream"))
+    rank, world = ctx["rank"], ctx["world"]
+    n, t, d = 16, 5, 5
+    B = 1 << args.log2_batch  # per GPU (weak scaling)
+    torch.manual_seed(0xC0FFEE01 + rank)  # synthetic inputs: canonical, uniform-ish field elements drawn on the device
+    coeffs = _rand_fr(torch, dev, B, d + 1)                         # [B][d+1][4] resident in HBM (this rank's shard)
+    shares = torch.empty((n, B, 4), dtype=torch.int64, device=dev)  # [n][B][4]
+    torch.cuda.synchronize()
+
+    def step():
+        rc = eng.dev_compute_shares(coeffs.data_ptr(), B, n, d, shares.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"hbmpc_dev_compute_shares -> {rc}: {eng.last_error()}")
+
     step()
     torch.cuda.synchronize()
     # the first secrets of the benchmarked buffers, for the oracle check inside the cpu_baseline leg
     check = (coeffs[:512].cpu().numpy().view(np.uint64), shares[:, :512].cpu().numpy().view(np.uint64))
-
-    # kernel time with HIP events on the launch stream (same region as the timed loop, separate pass)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for _ in range(args.warmup):
-        step()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
-
-    secs = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, barrier, max_reduce)
+    tm = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, ctx["barrier"], ctx["max_reduce"],
+                     prewarm_s=args.prewarm_seconds, events=ctx["events"]())
+    secs, kernel_ms = tm["secs"], tm["kernel_ms"]
     value = n * B * world * args.steps / secs
     algo_bytes = (d + 1 + n) * 32 * B
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
 
     out = {
         # BASELINE.json's metric, verbatim.  `value` is its compute_shares half on BASELINE configs[1] (one share = one
-        # evaluation of one secret's polynomial at one party's point); the batch_recon half is `recons_per_s` (N = 1)
+        # evaluation of one secret's polynomial at one party's point); the batch_recon half is `recon` / `recons_per_s`
         "metric": "shares/sec (compute_shares) + recons/sec (batch_recon), 256-bit Fr, 1/2/4/8 GPU",
         "value": value, "unit": "shares/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": secs / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
+        "prewarm_ms": tm["prewarm_ms"], "prewarm_steps": tm["prewarm_steps"],
         "config": {"workload": f"compute_shares n={n} t={t} batch=2^{args.log2_batch} secrets per GPU (BASELINE configs[1])",
                    "field": "bls12-381 Fr", "parallelism": f"batch-sharded x{world}, no data-path collective",
                    "field_impl": args.impl},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_eval_fft1<U29,4,6>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+                     "kernel": "k_eval_fft1<U29,4,6>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
+                     "kernel_ms_source": "HIP events around the K timed launches themselves"},
     }
-    tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr):
-        try:
-            rec = json.load(open(tr)).get(f"compute_shares_n{n}_d{d}_B2^{args.log2_batch}_{args.impl}")
-            if rec:
-                out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = rec["source"]
-        except Exception:
-            pass
+    rec = traffic_record(f"compute_shares_n{n}_d{d}_B2^{args.log2_batch}_{args.impl}")
+    if rec:
+        out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = rec["source"]
 
-    if rank == 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(n, d, 1 << args.cpu_sample_log2, check)
-        if not args.no_extra:
-            out["cpu_baseline_all_cores"] = cpu_baseline_threads(n, d, 1 << args.cpu_sample_log2)
-            out["extra"] = extra_measurements(eng, torch, dev, stream)
-            # the second half of BASELINE.json's metric, for convenience at the top level
-            out["recons_per_s"] = out["extra"]["cfg3_decode"]["recons_per_s"]
-            # context for `frac` (SURVEY 8(d): report against the vendor peak AND what the chip delivers): a plain
-            # device copy measured in this run, and the no-arithmetic kernel with exactly this kernel's traffic
-            # (27 % reads / 73 % writes, tools/ubench_store.hip, profiles/r01_store_pattern_ubench.txt)
-            out["roofline"]["peak_measured_copy_GBps"] = out["extra"]["device_copy_GBps"]
-            out["roofline"]["same_traffic_no_arithmetic_GBps"] = 4900.0
-            out["roofline"]["frac_of_same_traffic_floor"] = achieved / 4900.0
-    if world > 1 and args.final_gather:
+    final_gather = None
+    if world > 1 and not args.no_final_gather:
         # SURVEY 8(e) / north_star: "RCCL over xGMI used only for the final gather" -- outside the timed region
         from mpc_protocols_amd import sharding
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -223,13 +289,147 @@ def main():
         torch.cuda.synchronize()
         lo_b = rank * B
         assert torch.equal(full[:, lo_b:lo_b + B], shares)
-        out["final_gather"] = {"ms": g0.elapsed_time(g1), "bytes_per_rank": n * B * 32,
-                               "GBps_per_rank_received": n * B * 32 * (world - 1) / g0.elapsed_time(g1) / 1e6}
+        final_gather = {"ms": g0.elapsed_time(g1), "bytes_per_rank": n * B * 32,
+                        "GBps_per_rank_received": n * B * 32 * (world - 1) / g0.elapsed_time(g1) / 1e6,
+                        "collective": "all_gather of the [n][B] shares of every rank (RCCL)"}
         del full
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    del coeffs, shares
+
+    # ---- the recon half: batch_recover_secret on BASELINE configs[2], this rank's 2^20 chunks ----
+    n3, t3, d3, G = 31, 10, 10, 1 << args.log2_batch
+    torch.manual_seed(0xC0FFEE02 + rank)
+    x = _rand_fr(torch, dev, G, d3 + 1)
+    y = torch.empty((n3, G, 4), dtype=torch.int64, device=dev)
+    co = torch.empty((G, d3 + 1, 4), dtype=torch.int64, device=dev)
+    st = torch.empty((G,), dtype=torch.uint8, device=dev)
+    summ = torch.zeros((4,), dtype=torch.int32, device=dev)
+    ids = list(range(n3))
+    torch.cuda.synchronize()
+    assert eng.dev_vandermonde_apply(x.data_ptr(), G, n3, d3, y.data_ptr(), stream) == 0, eng.last_error()
+
+    def rstep():
+        rc = eng.dev_batch_recover(ids, y.data_ptr(), G, n3, d3, t3, co.data_ptr(), 0, st.data_ptr(), summ.data_ptr(), stream)
+        if rc != 0:
+            raise RuntimeError(f"hbmpc_dev_batch_recover -> {rc}: {eng.last_error()}")
+
+    rstep()
+    torch.cuda.synchronize()
+    assert bool((co == x).all()) and int(st.max()) == 0, "decode(encode(x)) != x"
+    rcheck = (y[:, :256].cpu().numpy().view(np.uint64), co[:256].cpu().numpy().view(np.uint64))
+    rtm = timed_steps(rstep, args.steps, args.warmup, torch.cuda.synchronize, ctx["barrier"], ctx["max_reduce"],
+                      prewarm_s=args.prewarm_seconds, events=ctx["events"]())
+    r_algo = (d3 + t3 + 1 + d3 + 1) * 32 * G
+    r_ach = r_algo / (rtm["kernel_ms"] * 1e-3) / 1e9
+    rk = "k_mfma_rows<11,1,12>" if args.recon_kernels == "mfma" and args.impl == "u29" else "k_batch_recover<U29,11,false>"
+    out["recon"] = {
+        "value": G * world * args.steps / rtm["secs"], "unit": "recons/s", "ms_per_step": rtm["secs"] / args.steps * 1e3,
+        "secrets_per_s": (d3 + 1) * G * world * args.steps / rtm["secs"],
+        "prewarm_ms": rtm["prewarm_ms"], "prewarm_steps": rtm["prewarm_steps"],
+        "config": {"workload": f"batch_recover_secret n={n3} t={t3} d={d3}, 2^{args.log2_batch} chunks per GPU, all {n3} senders "
+                               f"supplied, valid codewords (BASELINE configs[2])", "kernels": args.recon_kernels},
+        "roofline": {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_ach / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": rk, "kernel_ms": rtm["kernel_ms"], "algorithmic_bytes": r_algo,
+                     "note": "one decode call = the optimistic kernel + the (empty-list) fallback launches; kernel_ms covers the call"},
+    }
+    rec = traffic_record(f"batch_recover_n{n3}_d{d3}_t{t3}_G2^{args.log2_batch}_{args.recon_kernels}")
+    if rec:
+        out["recon"]["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
+        out["recon"]["roofline"]["traffic_source"] = rec["source"]
+    out["recons_per_s"] = out["recon"]["value"]
+    out["roofline_recon"] = out["recon"]["roofline"]
+    if final_gather:
+        out["final_gather"] = final_gather
+    del x, y, co, st
+
+    if rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline(n, d, 1 << args.cpu_sample_log2, check)
+        out["cpu_baseline_recon"] = cpu_baseline_recon(n3, d3, t3, 1 << 15, rcheck)
+        out["recon"]["cpu_baseline"] = out["cpu_baseline_recon"]
+        if not args.no_extra:
+            out["cpu_baseline_all_cores"] = cpu_baseline_threads(n, d, 1 << args.cpu_sample_log2)
+            out["extra"] = extra_measurements(eng, torch, dev, stream)
+            # context for `frac` (SURVEY 8(d): report against the vendor peak AND what the chip delivers): a plain
+            # device copy measured in this run, and -- a constant from an earlier measurement, not of this run -- the
+            # no-arithmetic kernel with exactly this kernel's traffic (27 % reads / 73 % writes)
+            out["roofline"]["peak_measured_copy_GBps"] = out["extra"]["device_copy_GBps"]
+            out["roofline"]["same_traffic_no_arithmetic_GBps_r01_constant"] = 4900.0
+            out["roofline"]["same_traffic_no_arithmetic_source"] = "tools/ubench_store.hip, profiles/r01_store_pattern_ubench.txt (not measured in this run)"
+    return out
+
+
+def bench_pipeline(ctx):
+    """BASELINE configs[3] / [4]: the triple_gen (2^22 triples) and fpmul (2^18 fixed-point muls) pipelines, n = 16,
+    t = 5, all 16 simulated parties of a batch element on one GPU and the batch sharded over the ranks (strong scaling:
+    independent preprocessing batches, reference honeybadger/mod.rs:1334-1393, triple_gen/triple_generation.rs:304-364);
+    no data-path collective, one all-gather of the result shares after the timed region."""
+    args, torch, dist, dev, eng, stream = (ctx[k] for k in ("args", "torch", "dist", "dev", "eng", "stream"))
+    rank, world = ctx["rank"], ctx["world"]
+    from __graft_entry__ import load_package
+    pl = load_package().pipelines
+    n, t = 16, 5
+    torch.manual_seed(0xC0FFEE03 + rank)
+    if args.workload == "cfg4":
+        m = 2 * t + 1
+        groups = (1 << 22) // m                      # chunks of 2t+1 triples (BatchRecon's unit)
+        lo, hi = shard_range(groups, rank, world)
+        N = (hi - lo) * m
+        tg = pl.TripleGen(eng, n, t, N, stream)
+        a, b, r = (_rand_fr(torch, dev, N) for _ in range(3))
+        _share_on_device(eng, torch, dev, stream, a, n, t, tg.a)
+        _share_on_device(eng, torch, dev, stream, b, n, t, tg.b)
+        _share_on_device(eng, torch, dev, stream, r, n, t, tg.rt)
+        _share_on_device(eng, torch, dev, stream, r, n, 2 * t, tg.r2t)
+        tg.run(check=True)                            # every decode reports zero failures
+        step, total, unit, pipe, result_ptr = (lambda: tg.run(check=False)), groups * m, "triples/s", tg, tg.c
+        what = f"triple_gen n={n} t={t}, {groups * m} Beaver triples (2^22 rounded to chunks of 2t+1), {N} on this rank"
+    else:
+        total = 1 << 18
+        lo, hi = shard_range(total, rank, world)
+        N, k, f = hi - lo, 16, 4
+        fp = setup_fpmul(eng, torch, dev, stream, n, t, N, k, f)
+        fp.run(check=True)
+        step, unit, pipe, result_ptr = fp.run, "fpmuls/s", fp, fp.out
+        what = f"fpmul n={n} t={t} (k, f) = ({k}, {f}), 2^18 fixed-point multiplications, {N} on this rank"
+    torch.cuda.synchronize()
+    tm = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, ctx["barrier"], ctx["max_reduce"],
+                     prewarm_s=args.prewarm_seconds, events=ctx["events"]())
+    out = {
+        "metric": "shares/sec (compute_shares) + recons/sec (batch_recon), 256-bit Fr, 1/2/4/8 GPU",
+        "value": total * args.steps / tm["secs"], "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": tm["secs"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic", "prewarm_ms": tm["prewarm_ms"], "prewarm_steps": tm["prewarm_steps"],
+        "device_ms_per_step": tm["kernel_ms"],
+        "config": {"workload": what + f" (BASELINE configs[{3 if args.workload == 'cfg4' else 4}])", "field": "bls12-381 Fr",
+                   "parallelism": f"batch-sharded x{world}, all {n} simulated parties of a shard on one GPU, no data-path collective"},
+    }
+    if world > 1 and not args.no_final_gather:
+        from mpc_protocols_amd import sharding
+        # this rank's result shares as a torch view of the pipeline's device buffer: [n][N][4]
+        mine = torch.empty((n, N, 4), dtype=torch.int64, device=dev)
+        eng.d2d(mine.data_ptr(), result_ptr, n * N * 32, stream)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        g0.record()
+        per_unit = (2 * t + 1) if args.workload == "cfg4" else 1
+        full = gather_ragged(sharding, dist, mine, total, per_unit)
+        g1.record()
+        torch.cuda.synchronize()
+        o = lo * per_unit
+        assert torch.equal(full[:, o:o + N], mine)
+        out["final_gather"] = {"ms": g0.elapsed_time(g1), "bytes_per_rank": n * N * 32,
+                               "collective": "all_gather of the [n][N_rank] result shares (RCCL)"}
+        del full, mine
+    pipe.close()
+    return out
+
+
+def gather_ragged(sharding, dist, mine, total, per_unit):
+    """all-gather of party-major shards whose lengths are shard_range(total / per_unit) * per_unit"""
+    n = mine.shape[0]
+    view = mine.reshape(n, mine.shape[1] // per_unit, per_unit * mine.shape[2])
+    full = sharding.gather_party_major(view, total // per_unit)
+    return full.reshape(n, total, mine.shape[2])
 
 
 def extra_measurements(eng, torch, dev, stream):

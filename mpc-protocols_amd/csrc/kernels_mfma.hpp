@@ -194,12 +194,15 @@ struct MfmaRowsArgs {
     uint32_t* flagged;
     uint32_t* counters;
     uint32_t* summary;    // decode only (nullable): initialised by workgroup 0
-    // Roles: the rows of the call cut into groups that fit the LDS.  Workgroups are dealt to roles in blocks of 8
-    // (block j of 8 consecutive workgroups -> role j % nroles) and workgroup b of role k walks the same tile sequence as
-    // workgroup b of every other role: workgroups b and b + 8 sit on the same XCD under round-robin placement, so the
-    // second role to touch a tile finds its input rows in that XCD's L2 (speed only, never correctness).
+    // Roles: the rows of the call cut into groups that fit the LDS -- the verify rows, then the output rows (kept
+    // together as far as they fit, so that all coefficients of a chunk are written through one XCD's L2).  Workgroups
+    // are dealt to roles in blocks of 8, in proportion to the roles' rows and interleaved: block j serves role
+    // blk_role[j] as its blk_idx[j]-th block.  Workgroups b and b + 8 sit on the same XCD under round-robin placement, so
+    // a role often finds the input rows of a tile in that XCD's L2 (speed only, never correctness).
     int nroles;
-    int wg_per_role;      // multiple of 8; grid = nroles * wg_per_role
+    int nblocks;          // grid = 8 * nblocks
+    int role_nwg[MF_MAX_ROLES];
+    uint8_t blk_role[64], blk_idx[64];
     MfmaRole role[MF_MAX_ROLES];
     int abl;              // microbenchmark ablations (tools/ubench_mfma.hip), 0 in the library: 1 = no epilogue arithmetic,
                           // 2 = no MFMAs, 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored
@@ -212,12 +215,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     constexpr int NT = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // role.nrows * ROWB
     if (a.summary && blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
-    const int blk8 = (int)blockIdx.x >> 3, role_id = blk8 % a.nroles;
-    const int wg_in_role = (blk8 / a.nroles) * 8 + ((int)blockIdx.x & 7);
+    const int blk8 = (int)blockIdx.x >> 3, role_id = a.blk_role[blk8];
+    const int wg_in_role = (int)a.blk_idx[blk8] * 8 + ((int)blockIdx.x & 7);
     MfmaRole role = a.role[0];
+    int role_wgs = a.role_nwg[0];
 #pragma unroll
     for (int k = 1; k < MF_MAX_ROLES; ++k)
-        if (k == role_id) role = a.role[k];
+        if (k == role_id) role = a.role[k], role_wgs = a.role_nwg[k];
     {
         const uint8_t* src = a.table + (size_t)role.row0 * ROWB;
         const int pieces = role.nrows * (ROWB / 16);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     // depend on the row index made hipcc peel the loop and copy the set at every merge; pulling the next tile into L2
     // with LDS-DMA loads into a scratch slot -- vmcnt is in-order, so the next wait for a claimed value then also waits
     // for the prefetch issued just before it: 0.44 ms instead of 0.36.)
-    const size_t tstep = (size_t)a.wg_per_role * WAVES;
+    const size_t tstep = (size_t)role_wgs * WAVES;
     const uint32_t in_lane_stride = a.in_chunk_major ? M * 32u : 32u;
     auto tile_chunks = [&](size_t t, uint32_t (&gg)[CG]) {
 #pragma unroll
@@ -358,31 +362,47 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     (void)pf;
 }
 
-// Host side: cut `rows` table rows (the first nv of them verify rows, kept together in role 0) into roles of at most
-// `cap` rows, as even as possible, and give every role wg_per_role workgroups (nwg / nroles rounded down to a multiple
-// of 8).  Returns false when the verify rows do not fit one role (the caller then uses the lane-per-chunk kernels).
+// Host side: cut `rows` table rows (the first nv of them verify rows) into roles of at most `cap` rows.  Everything in one
+// role when it fits; otherwise the verify rows form role 0 and the output rows are cut evenly into as few roles as
+// possible.  nwg workgroups (rounded down to blocks of 8, at most 64 blocks) are shared in proportion to the rows.
+// Returns false when the verify rows do not fit one role (the caller then uses the lane-per-chunk kernels).
 inline bool mf_plan_roles(int rows, int nv, int cap, int nwg, MfmaRowsArgs* a) {
     if (cap < 1 || nv > cap || rows < 1) return false;
-    const int nroles = (rows + cap - 1) / cap;
-    if (nroles > MF_MAX_ROLES) return false;
-    int per = (rows + nroles - 1) / nroles;
-    if (per < nv) per = nv;
-    int r = 0;
-    for (int k = 0; k < nroles; ++k) {
-        int take = k == nroles - 1 ? rows - r : per;
-        if (take > rows - r) take = rows - r;
-        if (take > cap || take < 1) return false;
-        a->role[k].row0 = r;
-        a->role[k].nrows = take;
-        r += take;
+    int nroles = 0;
+    if (rows <= cap) {
+        a->role[nroles++] = MfmaRole{0, rows};
+    } else {
+        if (nv > 0) a->role[nroles++] = MfmaRole{0, nv};
+        const int ow = rows - nv, parts = (ow + cap - 1) / cap, per = (ow + parts - 1) / parts;
+        for (int r = nv; r < rows; r += per) {
+            if (nroles == MF_MAX_ROLES) return false;
+            a->role[nroles++] = MfmaRole{r, rows - r < per ? rows - r : per};
+        }
     }
-    if (r != rows) return false;
     a->nroles = nroles;
-    int w = nwg / nroles / 8 * 8;
-    a->wg_per_role = w < 8 ? 8 : w;
+    int nblocks = nwg / 8;
+    nblocks = nblocks > 64 ? 64 : nblocks < nroles ? nroles : nblocks;
+    a->nblocks = nblocks;
+    // blocks per role in proportion to its rows (at least one), dealt out by largest remaining deficit
+    int have[MF_MAX_ROLES] = {0, 0, 0, 0};
+    for (int j = 0; j < nblocks; ++j) {
+        int best = 0;
+        double bestd = -1e30;
+        for (int k = 0; k < nroles; ++k) {
+            const double want = (double)(j + 1) * a->role[k].nrows / rows;
+            const double dfc = have[k] == 0 && nblocks - j <= nroles ? 1e9 : want - have[k];  // nobody is left without a block
+            if (dfc > bestd) bestd = dfc, best = k;
+        }
+        a->blk_role[j] = (uint8_t)best;
+        a->blk_idx[j] = (uint8_t)have[best]++;
+    }
+    for (int k = 0; k < nroles; ++k) {
+        if (have[k] == 0) return false;
+        a->role_nwg[k] = have[k] * 8;
+    }
     return true;
 }
-inline int mf_grid(const MfmaRowsArgs& a) { return a.nroles * a.wg_per_role; }
+inline int mf_grid(const MfmaRowsArgs& a) { return 8 * a.nblocks; }
 inline int mf_max_role_rows(const MfmaRowsArgs& a) {
     int m = 0;
     for (int k = 0; k < a.nroles; ++k) m = a.role[k].nrows > m ? a.role[k].nrows : m;

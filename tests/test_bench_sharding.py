@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
         return float(t.item())
 
     secs = bench.timed_steps(step, steps=5, warmup=2, sync_fn=lambda: None, barrier_fn=dist.barrier,
-                             max_reduce_fn=max_reduce)
+                             max_reduce_fn=max_reduce)["secs"]
     lo, hi = bench.shard_range(1000, rank, world)
     tot = torch.tensor([hi - lo], dtype=torch.int64)
     dist.all_reduce(tot)
@@ -98,3 +98,48 @@ def test_final_gather_world_size_2_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True, (7, 101, 4)), (1, True, (7, 101, 4))]
+
+
+def _cfg4_worker(rank, world, port, q):
+    """bench.py --workload cfg4 on CPU: the triple_gen batch sharded by chunks of 2t+1, every rank's result shares
+    computed from its shard alone (the oracle stands in for the device pipeline: [c]_t = rt + (a b - r) per party,
+    triple_generation.rs:196-208), then gather_ragged -- against the single-rank result of the whole batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from __graft_entry__ import load_package
+    from oracle import cref
+    load_package()
+    from mpc_protocols_amd import sharding
+    n, t, groups = 7, 2, 13                                  # 13 chunks of 2t+1 = 5 over 2 ranks: 7 + 6
+    m = 2 * t + 1
+    N = groups * m
+    a, b, r = cref.fill_random(1, N), cref.fill_random(2, N), cref.fill_random(3, N)
+    co = cref.fill_random(13, N * (t + 1)).reshape(N, t + 1, 4)
+    co[:, 0] = r
+    rc, srt = cref.compute_shares(co, n, t)                  # [n][N] sharings of r
+
+    def result(lo_e, hi_e):  # every party's [c]_t for elements [lo_e, hi_e), from those elements alone
+        opened = cref.fr_binop("sub", cref.fr_binop("mul", a[lo_e:hi_e], b[lo_e:hi_e]), r[lo_e:hi_e])
+        return np.stack([cref.triple_finalize(np.ascontiguousarray(srt[p, lo_e:hi_e]), opened)[1] for p in range(n)])
+
+    lo, hi = bench.shard_range(groups, rank, world)
+    mine = torch.from_numpy(result(lo * m, hi * m).view(np.int64))
+    got = bench.gather_ragged(sharding, dist, mine, N, m)
+    want = result(0, N)
+    q.put((rank, bool(np.array_equal(got.numpy().view(np.uint64), want)), tuple(got.shape), hi - lo))
+    dist.destroy_process_group()
+
+
+def test_cfg4_shard_and_gather_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 31) % 1000
+    procs = [ctx.Process(target=_cfg4_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, (7, 65, 4), 7), (1, True, (7, 65, 4), 6)]

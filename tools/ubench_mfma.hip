@@ -62,6 +62,15 @@ static void launch_rows(mf::MfmaRowsArgs a, int rows) {
         exit(2);
     }
     const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
+    static int shown = 0;
+    if (shown < 12 && a.G > 100000) {
+        ++shown;
+        fprintf(stderr, "   plan rows=%d nv=%d:", rows, a.nv);
+        for (int k = 0; k < a.nroles; ++k) fprintf(stderr, " role %d = rows [%d, %d) x %d workgroups;", k, a.role[k].row0, a.role[k].row0 + a.role[k].nrows, a.role_nwg[k]);
+        fprintf(stderr, " blocks:");
+        for (int j = 0; j < a.nblocks; ++j) fprintf(stderr, "%d", a.blk_role[j]);
+        fprintf(stderr, "\n");
+    }
     static bool attr_set = false;
     if (!attr_set) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
