@@ -86,6 +86,19 @@ typedef struct {
     uint32_t first_error;  /* its ShareErrorCode: what the reference's `?` would return  */
 } hbmpc_recover_summary;
 
+/* ---- Device buffers ----------------------------------------------------------------------
+ * Every *_dev pointer must be device memory that is coherent at kernel boundaries of a stream: hipMalloc (or an
+ * allocator that sub-allocates hipMalloc blocks, e.g. PyTorch's caching allocator), or hbmpc_dev_alloc.
+ * Memory from the stream-ordered pool (hipMallocAsync) is safe only while the pool RETAINS its blocks
+ * (hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, ...) above the working set).  With the default
+ * threshold 0 the pool returns freed blocks to the driver at every synchronisation and re-acquires them; on ROCm 7.2 /
+ * gfx950 kernels that use such a block next can read lines of its previous life and lose results to stale dirty lines
+ * (tests/cpp/test_pool_buffers.hip: every second decode of a re-allocated buffer set wrong, hipMalloc buffers in the
+ * same loop never; tools/repro_stale.hip for the isolated effect).  A multi-kernel call (batch_recover: optimistic
+ * kernel, then the fallback kernels through status bytes, lists and counters) cannot be made safe against that from
+ * inside; the library keeps its own scratch in hipMalloc memory and reads every atomically written hand-off word with
+ * agent-scope atomic loads.  Pointer attributes do not distinguish the two kinds, so nothing is rejected. */
+
 /* ---- context --------------------------------------------------------------------------- */
 /* device: HIP device ordinal (>= 0).  There is no CPU mode. */
 ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_out);

@@ -33,6 +33,7 @@ struct hbmpc_ctx {
     struct Tab {
         uint32_t* p = nullptr;
         bool pinned = false;  // referenced by a captured HIP graph: never evicted
+        std::array<size_t, 5> aux = {0, 0, 0, 0, 0};  // offsets inside the buffer (OEC/Gao tables): one unit with the table
     };
     struct Scratch {
         void* p = nullptr;
@@ -52,7 +53,6 @@ struct hbmpc_ctx {
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
     int n_cus = 256;
     int mfma_wgs = 0;                              // test aid: workgroups of a matrix-core launch (0 = one per CU)
-    std::map<std::string, std::array<size_t, 5>> layouts;  // offsets inside the OEC/Gao table buffers
     std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
     std::vector<std::pair<void*, size_t>> stage_free;  // device staging buffers of the host-pointer API, kept between calls
     size_t stage_bytes = 0;
@@ -88,13 +88,18 @@ static size_t ebytes(const hbmpc_ctx* ctx) { return impl_ebytes(ctx->impl); }
 #define REQ_GL(ctx) do { if ((ctx) && !is_gold(ctx)) return fail((ctx), TypeMismatch, "this context was created for bls12-381 Fr: hbmpc_gl_* needs a Goldilocks64 context"); } while (0)
 
 // ---- table cache -------------------------------------------------------------------------------
+// Looks the table up or builds it, all under ctx->mu.  `aux` (optional): in = what the builder computed alongside the
+// words (read after build() returns), out = what is stored with the table -- a table and its offsets are published
+// together, so a second thread that finds the table cached also finds its layout.
 template <class Build>
-static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build build, const uint32_t** out) {
+static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build build, const uint32_t** out,
+                                std::array<size_t, 5>* aux = nullptr) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->tables.find(key);
     if (it != ctx->tables.end()) {
         if (g_capturing) it->second.pinned = true;
         *out = it->second.p;
+        if (aux) *aux = it->second.aux;
         return ShareSuccess;
     }
     if (g_capturing) return fail(ctx, HBMPC_NO_DEVICE, "a table would have to be built during graph capture: run the call sequence once eagerly first");
@@ -113,7 +118,6 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
                 continue;
             }
             ctx->retired_tables.push_back(t->second.p);
-            ctx->layouts.erase(t->first);
             t = ctx->tables.erase(t);
         }
     }
@@ -122,7 +126,9 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
     uint32_t* dev = nullptr;
     HIP_TRY(ctx, hipMalloc(&dev, host.size() * 4));
     HIP_TRY(ctx, hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice));
-    ctx->tables[key].p = dev;
+    hbmpc_ctx::Tab& tab = ctx->tables[key];
+    tab.p = dev;
+    if (aux) tab.aux = *aux;
     *out = dev;
     return ShareSuccess;
 }

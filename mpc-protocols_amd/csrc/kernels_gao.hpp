@@ -159,7 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
     uint32_t* T1 = T0 + SUB * NL;
     uint32_t* BC = T1 + SUB * NL;             // broadcast slots: 4 elements
     int* iscr = reinterpret_cast<int*>(BC + 4 * NL);  // small int scratch (16 ints)
-    const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
+    const size_t count = a.counters ? handoff_count(a.counters, a.G) : a.G;
 
     for (size_t fi = (size_t)blockIdx.x * NSUB + sub; fi < count; fi += (size_t)gridDim.x * NSUB) {
         const size_t g = a.flagged ? (size_t)a.flagged[fi] : fi;
@@ -365,8 +365,10 @@ __global__ __launch_bounds__(BLOCK) void k_gao(GaoArgs a) {
         if (a.reset && threadIdx.x == 0) {
             const unsigned quorum = count ? (unsigned)std::min<size_t>((count + NSUB - 1) / NSUB, gridDim.x) : 1u;
             if (blockIdx.x < quorum && atomicAdd(&a.reset[3], 1u) == quorum - 1) {
-                if (a.summary && a.reset[2]) atomicAdd(&a.summary[0], a.reset[2]);
-                a.reset[0] = a.reset[1] = a.reset[2] = a.reset[3] = 0u;
+                const uint32_t tally = load_handoff(&a.reset[2]);
+                if (a.summary && tally) atomicAdd(&a.summary[0], tally);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) store_handoff(&a.reset[k], 0u);
             }
         }
     }
@@ -379,7 +381,7 @@ template <class F>
 HB_DEV void unscale_lane(const GaoArgs& a) {
     using E = typename F::E;
     constexpr int NL = F::NL, B = 8;
-    const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
+    const size_t count = a.counters ? handoff_count(a.counters, a.G) : a.G;
     const size_t f0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * B;
     if (f0 >= count) return;
     E one = F::cond_sub_r(F::mulc(F::load_const(a.one_plain), a.r2));  // 1 in Montgomery form
@@ -425,14 +427,16 @@ __global__ __launch_bounds__(64) void k_unscale(GaoArgs a) {
         // an idle block has nothing the reset could disturb -- if it runs late and reads a count that is already
         // zero it computes quorum 1 and is still idle.  No fence: nothing this block wrote needs publishing before
         // the ticket, and a working block's reads of the count precede its ticket in program order.
-        const size_t count = a.counters ? (size_t)a.counters[0] : a.G;
+        const size_t count = a.counters ? handoff_count(a.counters, a.G) : a.G;
         const size_t per_block = (size_t)blockDim.x * 8;
         const unsigned quorum = count ? (unsigned)((count + per_block - 1) / per_block) : 1u;
         if (blockIdx.x < quorum && atomicAdd(&a.reset[3], 1u) == quorum - 1) {
             // chunks the fused small-batch kernel repaired were tallied in reset[2] (the summary was still being
             // initialised then); every other writer of the summary finished with the previous kernel
-            if (a.summary && a.reset[2]) a.summary[0] += a.reset[2];
-            a.reset[0] = a.reset[1] = a.reset[2] = a.reset[3] = 0u;
+            const uint32_t tally = load_handoff(&a.reset[2]);
+            if (a.summary && tally) atomicAdd(&a.summary[0], tally);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store_handoff(&a.reset[k], 0u);
         }
     }
 }

@@ -336,7 +336,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                         uint32_t base = 0;
                         if (lane == leader) base = atomicAdd(a.counters, (uint32_t)__popcll(fm));
                         base = __shfl(base, leader);
-                        if (flag) a.flagged[base + __popcll(fm & ((1ull << lane) - 1ull))] = g[cg];
+                        const size_t slot = (size_t)base + __popcll(fm & ((1ull << lane) - 1ull));
+                        if (flag && slot < a.G) a.flagged[slot] = g[cg];  // the list has G entries (handoff_count)
                     }
                     if (live[cg] && h == 0) {
                         if (a.status) a.status[g[cg]] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the fallback kernels

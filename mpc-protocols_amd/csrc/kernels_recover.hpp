@@ -45,6 +45,24 @@ struct RecoverArgs {
                              // leaves it so, k_unscale)
     uint32_t* summary;       // {n_fallback, n_failed, first_failed, first_error}: initialised by block 0 of this kernel
 };
+// Words that one kernel of a call hands to the next and that are WRITTEN WITH ATOMICS (the flagged-chunk counters,
+// the summary) must be read with an agent-scope atomic load (global_load ... sc1), never with a plain or scalar load:
+// device-scope atomics execute at the memory side and neither update nor invalidate a copy of the line that another
+// XCD's L2 or the scalar cache still holds, so `a.counters[0]` as an s_load_dword can return the value from before the
+// previous kernel's atomicAdd.  Measured (tools/repro_stale.hip, profiles/r02_repro_stale_pool_memory.txt): with the
+// word in hipMallocAsync memory, 6 of 2400 first sequences after an allocation served stale values to s_load_dword /
+// plain global_load readers of an atomically incremented word -- every workgroup of the reading kernel, all of which
+// started after the writer had finished; never to sc1 loads or atomics, never when the writer was a plain store, never
+// in hipMalloc memory.  That is the round-1 failure ("k_gao dropped flagged chunks with pool scratch") -- the scratch
+// stays in hipMalloc memory AND the reads are sc1, so caller buffers from any allocator are safe too.
+HB_DEV uint32_t load_handoff(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+HB_DEV void store_handoff(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// number of entries of a flagged list: never more than the batch (a counter that did not start at zero -- a replayed
+// graph after a failed call -- must not index past the list)
+HB_DEV size_t handoff_count(const uint32_t* counter, size_t G) {
+    const size_t c = load_handoff(counter);
+    return c < G ? c : G;
+}
 // first kernel of a call: nothing else touches the summary before this kernel has finished
 HB_DEV void init_summary(const RecoverArgs& a) {
     if (blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
@@ -59,7 +77,8 @@ HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(a.counters, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
-    if (bad) a.flagged[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
+    const size_t slot = (size_t)base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (bad && slot < a.G) a.flagged[slot] = (uint32_t)g;  // the list has G entries (see handoff_count)
 }
 
 // M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers (9 M VGPRs).
@@ -266,7 +285,8 @@ HB_DEV void second_chance_one(const SecondArgs& a, size_t g, int& first) {
         first = w;
         return;
     }
-    a.flagged2[atomicAdd(&a.counters[1], 1u)] = (uint32_t)g;
+    const uint32_t slot = atomicAdd(&a.counters[1], 1u);
+    if (slot < a.G) a.flagged2[slot] = (uint32_t)g;
 }
 // The same decision with a whole wave per flagged chunk (lane = table row): used when the flagged list is short
 // enough to give every chunk a wave -- one lying share in a one-polynomial recover_secret then costs two dot
@@ -300,13 +320,16 @@ HB_DEV void second_chance_wave(const SecondArgs& a, size_t g, uint32_t* tally = 
         }
         return;
     }
-    if (lane == 0) a.flagged2[atomicAdd(&a.counters[1], 1u)] = (uint32_t)g;
+    if (lane == 0) {
+        const uint32_t slot = atomicAdd(&a.counters[1], 1u);
+        if (slot < a.G) a.flagged2[slot] = (uint32_t)g;
+    }
 }
 template <class F>
 __global__ __launch_bounds__(256) void k_second_chance(SecondArgs a) {
     // grid-stride over the flagged list: the launch is sized for a modest list and costs next to nothing when the
     // list is empty (the normal case)
-    const size_t count = a.counters[0];
+    const size_t count = handoff_count(a.counters, a.G);
     const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
     if (count <= nwaves && a.P - a.m <= 64 && a.m <= 64) {
         for (size_t fi = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); fi < count; fi += nwaves)
@@ -376,7 +399,10 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     const bool ok = __ballot(bad) == 0;
     if (lane == 0) {
         if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
-        if (!ok && !wa.fused) a.flagged[atomicAdd(a.counters, 1u)] = (uint32_t)g;
+        if (!ok && !wa.fused) {
+            const uint32_t slot = atomicAdd(a.counters, 1u);
+            if (slot < a.G) a.flagged[slot] = (uint32_t)g;
+        }
         else if (ok && a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
     }
     if (!ok) {

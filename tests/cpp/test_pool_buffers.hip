@@ -1,0 +1,157 @@
+// Caller buffers from the stream-ordered pool (hipMallocAsync): evals, coefficients, ncoeffs, status and summary of
+// hbmpc_dev_batch_recover all live in pool memory, EVERY chunk is flagged (one sender lies in every chunk, so the
+// optimistic kernel hands the whole batch to the fallback kernels through the counters / lists / status bytes), and
+// the buffers are freed, re-allocated and first used after an idle pause in every episode -- the conditions under
+// which an atomically written hand-off word was seen stale by plain loads (tools/repro_stale.hip).  Results must equal
+// the ones computed with hipMalloc buffers.  Three kernel families: wave-per-chunk (small batch), lane-per-chunk,
+// matrix cores; second chance on and off (OEC/Gao for every chunk).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <vector>
+
+#include "hbmpc_hip.h"
+#define CK(x)                                                                      \
+    do {                                                                           \
+        hipError_t e = (x);                                                        \
+        if (e != hipSuccess) {                                                     \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e)); \
+            exit(2);                                                               \
+        }                                                                          \
+    } while (0)
+#define OK(x)                                                                                   \
+    do {                                                                                        \
+        ShareErrorCode rc = (x);                                                                \
+        if (rc != ShareSuccess) {                                                               \
+            fprintf(stderr, "%s:%d %s -> %d: %s\n", __FILE__, __LINE__, #x, (int)rc, hbmpc_last_error(ctx)); \
+            exit(2);                                                                            \
+        }                                                                                       \
+    } while (0)
+
+static uint64_t g_state = 0x0123456789ABCDEFull;
+static uint64_t next64() {
+    uint64_t z = (g_state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+struct Bufs {
+    U256 *evals, *out;
+    uint32_t* nco;
+    uint8_t* st;
+    hbmpc_recover_summary* sum;
+};
+static Bufs alloc(bool pool, size_t n, size_t G, size_t m, hipStream_t s) {
+    Bufs b;
+    auto get = [&](void** p, size_t bytes) {
+        if (pool) CK(hipMallocAsync(p, bytes, s));
+        else CK(hipMalloc(p, bytes));
+    };
+    get((void**)&b.evals, n * G * 32), get((void**)&b.out, G * m * 32), get((void**)&b.nco, G * 4), get((void**)&b.st, G), get((void**)&b.sum, 64);
+    return b;
+}
+static void release(bool pool, Bufs& b, hipStream_t s) {
+    for (void* p : {(void*)b.evals, (void*)b.out, (void*)b.nco, (void*)b.st, (void*)b.sum}) {
+        if (pool) CK(hipFreeAsync(p, s));
+        else CK(hipFree(p));
+    }
+}
+
+int main() {
+    hbmpc_ctx* ctx = nullptr;
+    if (hbmpc_create(0, Bls12_381Fr, &ctx) != ShareSuccess) {
+        fprintf(stderr, "no device\n");
+        return 2;
+    }
+    void* vs = nullptr;
+    OK(hbmpc_stream_create(ctx, &vs));
+    hipStream_t s = (hipStream_t)vs;
+    const size_t n = 16, t = 5, d = 5, m = d + 1;
+    int failures = 0;
+    // include/hbmpc_hip.h, "Device buffers": pool memory is supported when the pool RETAINS freed blocks.  With the
+    // default release threshold (0) the pool returns its memory to the driver at every synchronisation and re-acquires
+    // it; kernels that then use it were seen to read lines of its previous life and to lose results to stale dirty lines
+    // (ROCm 7.2, gfx950: every second episode of this very test; hipMalloc buffers in the same loop never) -- a platform
+    // matter no library can repair from inside.  POOL_DEFAULT_THRESHOLD=1 runs the test in that configuration.
+    if (!getenv("POOL_DEFAULT_THRESHOLD")) {
+        hipMemPool_t pool;
+        CK(hipDeviceGetDefaultMemPool(&pool, 0));
+        uint64_t thr = ~0ull;
+        CK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
+        printf("release threshold of the default pool raised: freed blocks stay in the pool\n");
+    } else {
+        printf("default release threshold: the pool returns freed blocks to the driver at every synchronisation\n");
+    }
+    struct Case {
+        const char* name;
+        size_t G;
+        int mfma, second;
+    } cases[] = {{"wave-per-chunk, second chance", 700, 0, 1},  {"wave-per-chunk, OEC/Gao", 700, 0, 0},
+                 {"lane-per-chunk, second chance", 20000, 0, 1}, {"lane-per-chunk, OEC/Gao", 20000, 0, 0},
+                 {"matrix cores, second chance", 20000, 1, 1},   {"matrix cores, OEC/Gao", 20000, 1, 0}};
+    for (const Case& c : cases) {
+        const size_t G = c.G;
+        OK(hbmpc_set_matrix_cores(ctx, c.mfma, 1));
+        OK(hbmpc_set_second_chance(ctx, c.second));
+        // valid codewords, then sender 3 lies in every chunk
+        std::vector<U256> coeffs(G * m), shares(n * G);
+        for (auto& v : coeffs) v = U256{{next64(), next64(), next64(), next64() % 0x73eda753299d7d48ULL}};
+        OK(hbmpc_compute_shares(ctx, coeffs.data(), G, n, d, shares.data()));
+        for (size_t g = 0; g < G; ++g) shares[3 * G + g].data[0] ^= 1;
+        size_t ids[16];
+        for (size_t i = 0; i < n; ++i) ids[i] = i;
+        std::vector<U256> want(G * m), got(G * m);
+        std::vector<uint32_t> want_n(G), got_n(G);
+        std::vector<uint8_t> want_s(G), got_s(G);
+        hbmpc_recover_summary want_sum, got_sum;
+        for (int pool = 0; pool < 3; ++pool) {  // 0: the reference run, 1: pool buffers, 2: hipMalloc buffers, same episodes
+            const int episodes = pool ? 25 : 1;
+            for (int ep = 0; ep < episodes; ++ep) {
+                Bufs b = alloc(pool == 1, n, G, m, s);
+                CK(hipMemcpyAsync(b.evals, shares.data(), n * G * 32, hipMemcpyHostToDevice, s));
+                CK(hipMemsetAsync(b.out, 0xEE, G * m * 32, s));
+                CK(hipMemsetAsync(b.st, 0x77, G, s));
+                OK(hbmpc_dev_batch_recover(ctx, ids, n, b.evals, G, n, d, t, b.out, b.nco, b.st, b.sum, s));
+                std::vector<U256>& o = pool ? got : want;
+                CK(hipMemcpyAsync(o.data(), b.out, G * m * 32, hipMemcpyDeviceToHost, s));
+                CK(hipMemcpyAsync((pool ? got_n : want_n).data(), b.nco, G * 4, hipMemcpyDeviceToHost, s));
+                CK(hipMemcpyAsync((pool ? got_s : want_s).data(), b.st, G, hipMemcpyDeviceToHost, s));
+                CK(hipMemcpyAsync(pool ? &got_sum : &want_sum, b.sum, sizeof(hbmpc_recover_summary), hipMemcpyDeviceToHost, s));
+                CK(hipStreamSynchronize(s));
+                release(pool == 1, b, s);
+                CK(hipStreamSynchronize(s));
+                if (!pool) {
+                    // the reference result itself: every chunk repaired by the fallback, polynomial recovered
+                    bool ok = memcmp(want.data(), coeffs.data(), G * m * 32) == 0 && want_sum.n_fallback == G && want_sum.n_failed == 0;
+                    for (size_t g = 0; g < G; ++g) ok = ok && want_s[g] == 1;
+                    if (!ok) {
+                        printf("  FAILED %s: hipMalloc buffers: not every chunk repaired (n_fallback %u, n_failed %u)\n", c.name, want_sum.n_fallback, want_sum.n_failed);
+                        ++failures;
+                    }
+                } else {
+                    size_t bad_st = 0;
+                    for (size_t g = 0; g < G; ++g) bad_st += got_s[g] != want_s[g];
+                    if (memcmp(got.data(), want.data(), G * m * 32) != 0 || memcmp(got_n.data(), want_n.data(), G * 4) != 0 || bad_st ||
+                        memcmp(&got_sum, &want_sum, sizeof got_sum) != 0) {
+                        printf("  FAILED %s: %s buffers, episode %d: %zu status bytes differ, n_fallback %u (want %u)\n", c.name, pool == 1 ? "pool" : "hipMalloc", ep, bad_st,
+                               got_sum.n_fallback, want_sum.n_fallback);
+                        ++failures;
+                    }
+                    usleep(2000);
+                }
+            }
+        }
+        printf("%s: G = %zu, every chunk flagged, 25 episodes with pool buffers %s\n", c.name, G, failures ? "(failures so far)" : "ok");
+    }
+    hbmpc_destroy(ctx);
+    if (failures) {
+        printf("%d FAILED\n", failures);
+        return 1;
+    }
+    printf("pool buffers passed\n");
+    return 0;
+}

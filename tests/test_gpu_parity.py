@@ -416,6 +416,47 @@ def test_one_context_many_threads(eng):
     assert not errs, errs[:2]
 
 
+def test_threads_race_on_new_sender_sets(eng):
+    """Two threads decode the SAME sender set, never seen before, at the same moment -- the OEC/Gao table and its
+    layout (round count, offsets) must reach the cache as one unit: a thread that finds the table cached with a
+    default-constructed layout would run zero OEC rounds and report every flagged chunk as DecodingError.  Second chance
+    off, so that every corrupted chunk goes through the OEC/Gao kernel that reads that layout."""
+    import threading
+    n, t, d, G = 13, 4, 3, 48
+    eng.set_second_chance(False)
+    try:
+        for trial in range(24):
+            rng = np.random.default_rng(9000 + trial)
+            S = int(rng.integers(d + t + 2, n + 1))
+            ids = [int(i) for i in rng.permutation(n)[:S]]            # a fresh subset / order almost every trial
+            x = rnd(2000 + trial, G, d + 1)
+            rc, y = O.vandermonde_apply(x, n, d)
+            ev = np.ascontiguousarray(y[ids])
+            ev[ids.index(min(ids)), :, 0] ^= np.uint64(1)             # the lowest id (inside the interpolation set) lies in every chunk
+            want = O.batch_recover(ids, ev, n, d, t)
+            assert want[0] == 0 and (want[3] == 1).all()
+            barrier = threading.Barrier(2)
+            res, errs = [None, None], []
+
+            def worker(k):
+                try:
+                    barrier.wait()
+                    res[k] = eng.batch_recover(ids, ev, n, d, t)
+                except Exception as e:  # noqa: BLE001
+                    errs.append(repr(e))
+
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+            for q in th:
+                q.start()
+            for q in th:
+                q.join()
+            assert not errs, errs
+            for got in res:
+                assert got[0] == want[0] and all(np.array_equal(u, v) for u, v in zip(got[1:], want[1:])), trial
+    finally:
+        eng.set_second_chance(True)
+
+
 def test_buffers_beyond_4_gib(eng):
     """10.5 M secrets, n = 16: the share buffer is 5.4 GB, so every byte offset past 2^32 is exercised (64-bit
     indexing in the staging, the party-major stores and the decode's row addressing).  Checked by the
