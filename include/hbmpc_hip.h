@@ -119,6 +119,24 @@ ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream); /* stream == NUL
 ShareErrorCode hbmpc_stream_create(hbmpc_ctx* ctx, void** stream_out); /* a non-blocking hipStream_t on the ctx's device */
 ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream);
 
+/* ---- multi-GPU: the final gather ---------------------------------------------------------
+ * The path shards by batch index (reference: independent preprocessing sessions,
+ * honeybadger/mod.rs:1334-1393): a host drives one ctx per device, every ctx computes the party-major outputs
+ * [n_rows][counts[r]] of its contiguous slice of the batch, and nothing crosses devices until the consumer wants
+ * the rows of the WHOLE batch in one place.  This call is that step for a single-process host (a Rust node owns all
+ * its devices; no RCCL bootstrap, no collective: it is a gather of disjoint column ranges, one peer copy per row
+ * and shard over xGMI):
+ *   shards_dev[r]   on the device of ctxs[r]: [n_rows][strides[r]] elements, the first counts[r] of each row valid
+ *   out_dev         on the device of ctxs[root]: [n_rows][out_stride]; shard r lands at column sum(counts[0..r))
+ * Elements are those of the contexts' field (all ctxs must share it).  The copies are enqueued on `stream` of the
+ * root (NULL = its own stream) after the streams of all source contexts have been drained (sync_sources != 0), or
+ * immediately when the caller has ordered them itself (sync_sources = 0).  Peer access root <- source is enabled
+ * on first use when the devices differ. */
+ShareErrorCode hbmpc_dev_gather_party_major(hbmpc_ctx* const* ctxs, size_t n_shards, size_t root,
+                                            const void* const* shards_dev, const size_t* counts, const size_t* strides,
+                                            size_t n_rows, void* out_dev, size_t out_stride, int sync_sources,
+                                            void* stream);
+
 /* ---- HIP graphs (for hosts without their own HIP binding) ----------------------------------------
  * The reference's regime is many small protocol steps (a few hundred elements per message); a device-resident
  * pipeline of hbmpc_dev_* calls is then bound by kernel-launch overhead.  Every hbmpc_dev_* call is capturable
@@ -313,6 +331,12 @@ ShareErrorCode hbmpc_dev_truncpr_finalize_parties(hbmpc_ctx* ctx, const U256* a,
  * op: 0 = a + b, 1 = a - b, 2 = a * b (element-wise, N elements). */
 ShareErrorCode hbmpc_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out);
 ShareErrorCode hbmpc_dev_fr_op(hbmpc_ctx* ctx, int op, const U256* a, const U256* b, size_t N, U256* out, void* stream);
+/* share (+, -, *) ONE field element and element - share: Add<F>, Sub<F>, Mul<F>, from_scalar_sub of common/mod.rs:205-280.
+ * op: 0 = a + s, 1 = a - s, 2 = a * s, 3 = s - a.  `scalar` points to one canonical element in HOST memory in both
+ * variants (it travels in the kernel arguments); a non-canonical scalar is InvalidInput. */
+ShareErrorCode hbmpc_fr_op_scalar(hbmpc_ctx* ctx, int op, const U256* a, const U256* scalar, size_t N, U256* out);
+ShareErrorCode hbmpc_dev_fr_op_scalar(hbmpc_ctx* ctx, int op, const U256* a_dev, const U256* scalar_host, size_t N,
+                                      U256* out_dev, void* stream);
 
 /* ==== wire codec: ark-serialize "compressed" payloads of the path ====
  * Vec<F>  = u64-LE length, then 32-byte LE canonical elements (EvalBatch / RevealBatch payloads,
@@ -432,6 +456,9 @@ ShareErrorCode hbmpc_gl_nonrobust_recover_secret(hbmpc_ctx* ctx, const size_t* i
                                                  const uint64_t* vals, size_t S, size_t n, uint64_t* coeffs_out,
                                                  size_t* ncoeffs_out, uint64_t* secret_out);
 ShareErrorCode hbmpc_gl_fr_op(hbmpc_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t N, uint64_t* out);
+ShareErrorCode hbmpc_gl_fr_op_scalar(hbmpc_ctx* ctx, int op, const uint64_t* a, const uint64_t* scalar, size_t N, uint64_t* out);
+ShareErrorCode hbmpc_gl_dev_fr_op_scalar(hbmpc_ctx* ctx, int op, const uint64_t* a_dev, const uint64_t* scalar_host, size_t N,
+                                         uint64_t* out_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_fr_op(hbmpc_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, size_t N, uint64_t* out,
                                   void* stream);
 ShareErrorCode hbmpc_gl_triple_local(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, size_t N,

@@ -324,6 +324,52 @@ extern "C" ShareErrorCode hbmpc_stream_create(hbmpc_ctx* ctx, void** stream_out)
     *stream_out = s;
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_dev_gather_party_major(hbmpc_ctx* const* ctxs, size_t n_shards, size_t root,
+                                                       const void* const* shards_dev, const size_t* counts,
+                                                       const size_t* strides, size_t n_rows, void* out_dev, size_t out_stride,
+                                                       int sync_sources, void* stream) {
+    if (!ctxs || n_shards == 0 || root >= n_shards || !ctxs[root]) return InvalidInput;
+    hbmpc_ctx* rc_ctx = ctxs[root];
+    if (!shards_dev || !counts || !strides || !out_dev) return fail(rc_ctx, InvalidInput, "null argument");
+    size_t total = 0;
+    for (size_t r = 0; r < n_shards; ++r) {
+        if (!ctxs[r]) return fail(rc_ctx, InvalidInput, "null context in the shard list");
+        if (is_gold(ctxs[r]) != is_gold(rc_ctx)) return fail(rc_ctx, TypeMismatch, "contexts of different fields");
+        if (strides[r] < counts[r]) return fail(rc_ctx, InvalidInput, "shard row stride below its column count");
+        if (counts[r] && !shards_dev[r]) return fail(rc_ctx, InvalidInput, "null shard");
+        total += counts[r];
+    }
+    if (out_stride < total) return fail(rc_ctx, InvalidInput, "output row stride below the total column count");
+    const size_t eb = ebytes(rc_ctx);
+    if (sync_sources) {
+        for (size_t r = 0; r < n_shards; ++r) {
+            HIP_TRY(rc_ctx, hipSetDevice(ctxs[r]->device));
+            HIP_TRY(rc_ctx, hipStreamSynchronize(ctxs[r]->stream));
+        }
+    }
+    HIP_TRY(rc_ctx, hipSetDevice(rc_ctx->device));
+    hipStream_t s = pick(rc_ctx, stream);
+    size_t col = 0;
+    for (size_t r = 0; r < n_shards; ++r) {
+        const int src_dev = ctxs[r]->device;
+        if (src_dev != rc_ctx->device) {
+            int can = 0;
+            HIP_TRY(rc_ctx, hipDeviceCanAccessPeer(&can, rc_ctx->device, src_dev));
+            if (can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(src_dev, 0);  // idempotent across calls
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(rc_ctx, e);
+                (void)hipGetLastError();
+            }
+        }
+        for (size_t j = 0; j < n_rows && counts[r]; ++j) {
+            char* dst = (char*)out_dev + (j * out_stride + col) * eb;
+            const char* src = (const char*)shards_dev[r] + j * strides[r] * eb;
+            HIP_TRY(rc_ctx, hipMemcpyPeerAsync(dst, rc_ctx->device, src, src_dev, counts[r] * eb, s));
+        }
+        col += counts[r];
+    }
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream) {
     if (!ctx || !stream) return InvalidInput;
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
@@ -828,6 +874,38 @@ static ShareErrorCode fr_op_any(hbmpc_ctx* ctx, int op, const void* a, const voi
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
+// scalar: ONE canonical element in HOST memory
+static ShareErrorCode fr_op_scalar_any(hbmpc_ctx* ctx, int op, const void* a, const void* scalar, size_t N, void* out, void* stream) {
+    if (ctx && !scalar) return fail(ctx, InvalidInput, "null scalar");
+    ELEM_PROLOGUE
+    if (op < 0 || op > 3) return fail(ctx, InvalidInput, "op must be 0 (a + s), 1 (a - s), 2 (a * s) or 3 (s - a)");
+    ScalarArg sc;
+    memset(&sc, 0, sizeof sc);
+    memcpy(sc.w, scalar, ebytes(ctx));
+    if (ctx->impl == IMPL_GOLD) {
+        uint64_t v;
+        memcpy(&v, scalar, 8);
+        if (v >= HGl::P) return fail(ctx, InvalidInput, "scalar is not a canonical field element");
+    } else {
+        uint64_t v[4];
+        memcpy(v, scalar, 32);
+        if (HFr::geq(v)) return fail(ctx, InvalidInput, "scalar is not a canonical field element");
+    }
+    const ElemConsts cs = elem_consts(ctx->impl);
+#define SCALAR_OPS(F)                                                                                                       \
+    do {                                                                                                                    \
+        if (op == 0) hipLaunchKernelGGL((k_scalarop<F, OP_ADD>), dim3(grid), dim3(256), 0, s, W(a), sc, N, cs, WO(out));    \
+        if (op == 1) hipLaunchKernelGGL((k_scalarop<F, OP_SUB>), dim3(grid), dim3(256), 0, s, W(a), sc, N, cs, WO(out));    \
+        if (op == 2) hipLaunchKernelGGL((k_scalarop<F, OP_MUL>), dim3(grid), dim3(256), 0, s, W(a), sc, N, cs, WO(out));    \
+        if (op == 3) hipLaunchKernelGGL((k_scalarop<F, OP_RSUB>), dim3(grid), dim3(256), 0, s, W(a), sc, N, cs, WO(out));   \
+    } while (0)
+    if (ctx->impl == IMPL_GOLD) SCALAR_OPS(Gold);
+    else if (ctx->impl == IMPL_U29) SCALAR_OPS(U29);
+    else SCALAR_OPS(Sat32);
+#undef SCALAR_OPS
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
 static ShareErrorCode triple_local_any(hbmpc_ctx* ctx, const void* a, const void* b, const void* r2t, size_t N, void* out,
                                        void* stream) {
     ELEM_PROLOGUE
@@ -861,6 +939,11 @@ static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const v
                                              void* stream) {                                                             \
         REQ(ctx);                                                                                                        \
         return fr_op_any(ctx, op, a, b, N, out, stream);                                                                 \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_fr_op_scalar(hbmpc_ctx* ctx, int op, const T* a, const T* scalar_host, size_t N,  \
+                                                    T* out, void* stream) {                                              \
+        REQ(ctx);                                                                                                        \
+        return fr_op_scalar_any(ctx, op, a, scalar_host, N, out, stream);                                                \
     }                                                                                                                    \
     extern "C" ShareErrorCode PFX##dev_triple_local(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t, size_t N,      \
                                                     T* out, void* stream) {                                              \
@@ -1006,6 +1089,11 @@ typedef std::vector<void*> VO;
         REQ(ctx);                                                                                                        \
         return elem_host(ctx, {{a, N}, {b, N}}, {{out, N}},                                                              \
                          [&](VI& i, VO& o) { return fr_op_any(ctx, op, i[0], i[1], N, o[0], nullptr); });                \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##fr_op_scalar(hbmpc_ctx* ctx, int op, const T* a, const T* scalar, size_t N, T* out) {  \
+        REQ(ctx);                                                                                                        \
+        return elem_host(ctx, {{a, N}}, {{out, N}},                                                                      \
+                         [&](VI& i, VO& o) { return fr_op_scalar_any(ctx, op, i[0], scalar, N, o[0], nullptr); });       \
     }                                                                                                                    \
     extern "C" ShareErrorCode PFX##triple_local(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t, size_t N, T* out) { \
         REQ(ctx);                                                                                                        \

@@ -41,6 +41,30 @@ __global__ __launch_bounds__(256) void k_binop(const uint32_t* __restrict__ a, c
     }
 }
 
+// share (+,-,*) ONE field element, and element - share (common/mod.rs:205-280: Add<F>, Sub<F>, Mul<F>,
+// from_scalar_sub): the scalar travels in the kernel arguments, nobody materialises N copies of it
+enum { OP_RSUB = 3 };
+struct ScalarArg {
+    alignas(16) uint32_t w[8];  // canonical element (Goldilocks: the first two words)
+};
+template <class F, int OP>
+__global__ __launch_bounds__(256) void k_scalarop(const uint32_t* __restrict__ a, ScalarArg sc, size_t N, ElemConsts cs,
+                                                  uint32_t* __restrict__ out) {
+    using E = typename F::E;
+    HB_GID
+    const E x = F::load(a + i * F::EW), y = F::load(sc.w);
+    if constexpr (OP == OP_ADD) {
+        F::store_loose(out + i * F::EW, F::add(x, y));
+    } else if constexpr (OP == OP_SUB) {
+        F::store_loose(out + i * F::EW, F::template sub<2>(x, y));
+    } else if constexpr (OP == OP_RSUB) {
+        F::store_loose(out + i * F::EW, F::template sub<2>(y, x));
+    } else {
+        const E ym = F::mulc(y, cs.r2);
+        F::store_lt2r(out + i * F::EW, F::mont(x, ym));
+    }
+}
+
 // triple_gen/triple_generation.rs:333-340:  out = a*b - r2t
 template <class F>
 __global__ __launch_bounds__(256) void k_triple_local(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,

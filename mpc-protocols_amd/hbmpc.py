@@ -113,6 +113,18 @@ class Engine:
     def set_small_batch_chunks(self, max_chunks: int):
         assert self.L.hbmpc_set_small_batch_chunks(self.ctx, C.c_size_t(max_chunks)) == 0
 
+    @staticmethod
+    def gather_party_major(engines, root, shards_d, counts, strides, n_rows, out_d, out_stride, sync_sources=True, stream=0):
+        """hbmpc_dev_gather_party_major: one engine (context) per shard; device pointers as ints"""
+        k = len(engines)
+        ctxs = (C.c_void_p * k)(*[e.ctx for e in engines])
+        ptrs = (C.c_void_p * k)(*shards_d)
+        cnt = (C.c_size_t * k)(*counts)
+        strd = (C.c_size_t * k)(*strides)
+        return engines[root].L.hbmpc_dev_gather_party_major(ctxs, C.c_size_t(k), C.c_size_t(root), ptrs, cnt, strd, C.c_size_t(n_rows),
+                                                            C.c_void_p(out_d), C.c_size_t(out_stride), C.c_int(1 if sync_sources else 0),
+                                                            C.c_void_p(stream))
+
     def set_matrix_cores(self, on: bool, min_chunks: int = 0):
         """large Fr decodes on the matrix cores (int8 MFMA); min_chunks = 0 keeps the current threshold"""
         assert self.L.hbmpc_set_matrix_cores(self.ctx, C.c_int(1 if on else 0), C.c_size_t(min_chunks)) == 0
@@ -289,6 +301,20 @@ class Engine:
     def d2d(self, dst: int, src: int, nbytes: int, stream=0):
         rc = self.L.hbmpc_memcpy_d2d(self.ctx, C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), C.c_void_p(stream))
         assert rc == 0, self.last_error()
+
+    def fr_op_scalar(self, op, a, scalar):
+        """op: "add" (a + s), "sub" (a - s), "mul" (a * s), "rsub" (s - a); scalar: one element"""
+        a = np.ascontiguousarray(a)
+        sc = np.ascontiguousarray(scalar)
+        out = self._new((a.shape[0],))
+        rc = self._f("fr_op_scalar")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2, "rsub": 3}[op]), _p(a), _p(sc),
+                                       C.c_size_t(a.shape[0]), _p(out))
+        return rc, out
+
+    def dev_fr_op_scalar(self, op, a_d, scalar, N, out_d, stream=0):
+        sc = np.ascontiguousarray(scalar)
+        return self._f("dev_fr_op_scalar")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2, "rsub": 3}[op]), C.c_void_p(a_d),
+                                             _p(sc), C.c_size_t(N), C.c_void_p(out_d), C.c_void_p(stream))
 
     def dev_fr_op(self, op, a_d, b_d, N, out_d, stream=0):
         return self._f("dev_fr_op")(self.ctx, C.c_int({"add": 0, "sub": 1, "mul": 2}[op]), C.c_void_p(a_d),

@@ -56,6 +56,20 @@ def test_field_ops(eng):
         assert [int(x) for x in got] == [fn(x, y) for x, y in zip(ai, bi)], op
 
 
+def test_scalar_ops(eng):
+    """Add<F>, Sub<F>, Mul<F>, from_scalar_sub (common/mod.rs:205-280) over the small field"""
+    a = rnd(3, 900)
+    a[:len(EDGE)] = np.array(EDGE, dtype=np.uint64)
+    ai = [int(x) for x in a]
+    for sv in EDGE + [int(rnd(4, 1)[0])]:
+        sc = np.array([sv], dtype=np.uint64)
+        for op, fn in (("add", lambda x: (x + sv) % P), ("sub", lambda x: (x - sv) % P), ("mul", lambda x: x * sv % P),
+                       ("rsub", lambda x: (sv - x) % P)):
+            rc, got = eng.fr_op_scalar(op, a, sc)
+            assert rc == 0 and [int(x) for x in got] == [fn(x) for x in ai], (op, sv)
+    assert eng.fr_op_scalar("add", a, np.array([P], dtype=np.uint64))[0] == 4   # not canonical
+
+
 def test_context_serves_one_field(eng):
     fr = load_package().Engine(0)
     x = np.zeros((4, 3), dtype=np.uint64)

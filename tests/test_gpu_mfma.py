@@ -154,3 +154,42 @@ def test_full_size_config3(eng):
     ti = torch.as_tensor(idx, device=dev)
     assert np.array_equal(co[ti].cpu().numpy().view(np.uint64), co0) and np.array_equal(st[ti].cpu().numpy(), st0)
     assert np.array_equal(nco[ti].cpu().numpy().view(np.uint32), nco0)
+
+
+def test_gather_party_major_two_contexts():
+    """hbmpc_dev_gather_party_major: two contexts (here both on device 0; on a multi-GPU node one per device) compute the
+    shares of their contiguous slices of a batch; the gather puts the party-major rows of the whole batch on the root.
+    Ragged slices, strided shard rows, against the single-context result."""
+    import torch
+    pkg = load_package()
+    e0, e1 = pkg.Engine(0), pkg.Engine(0)
+    try:
+        n, d, B = 16, 5, 1001
+        coeffs = rnd(321, B, d + 1)
+        rc, want = O.compute_shares(coeffs, n, d)
+        lo = 517                                           # slices of 517 and 484 secrets
+        dev = torch.device("cuda", 0)
+        cz = torch.from_numpy(coeffs.view(np.int64)).to(dev)
+        s0 = torch.empty((n, lo + 3, 4), dtype=torch.int64, device=dev)          # row stride 520 > 517 columns
+        s1 = torch.empty((n, B - lo, 4), dtype=torch.int64, device=dev)
+        out = torch.full((n, B + 5, 4), -1, dtype=torch.int64, device=dev)
+        c0, c1 = cz[:lo].contiguous(), cz[lo:].contiguous()
+        torch.cuda.synchronize()
+        assert e0.dev_vandermonde_apply_strided(c0.data_ptr(), lo, n, d, s0.data_ptr(), lo + 3) == 0
+        assert e1.dev_compute_shares(c1.data_ptr(), B - lo, n, d, s1.data_ptr()) == 0
+        rc = pkg.Engine.gather_party_major([e0, e1], 0, [s0.data_ptr(), s1.data_ptr()], [lo, B - lo], [lo + 3, B - lo], n,
+                                           out.data_ptr(), B + 5)
+        assert rc == 0, e0.last_error()
+        e0.sync()
+        got = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got[:, :B], want) and (got[:, B:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        # argument checks: stride below count, field mismatch
+        assert pkg.Engine.gather_party_major([e0, e1], 0, [s0.data_ptr(), s1.data_ptr()], [lo, B - lo], [lo - 1, B - lo], n,
+                                             out.data_ptr(), B + 5) == 4
+        g = pkg.Engine(0, field="goldilocks")
+        assert pkg.Engine.gather_party_major([e0, g], 0, [s0.data_ptr(), s1.data_ptr()], [lo, B - lo], [lo + 3, B - lo], n,
+                                             out.data_ptr(), B + 5) == 5
+        g.close()
+    finally:
+        e0.close()
+        e1.close()

@@ -72,6 +72,25 @@ def test_field_ops(eng_all):
         assert GU.eq(got, O.fr_binop(op, a, b)), op
 
 
+def test_scalar_ops(eng_all):
+    """share (+, -, *) one field element and element - share (common/mod.rs:205-280; oracle/spec.py:219-232): the
+    scalar-broadcast entry points against the big-int restatement, edge values on both sides"""
+    e = eng_all
+    edge = [0, 1, 2, R - 1, R - 2, (1 << 255) % R, 1 << 254, R >> 1, 0xFFFFFFFF, (1 << 232) - 1, (1 << 29) - 1, R - (1 << 29)]
+    a = rnd(5, 700)
+    a[:len(edge)] = O.ints_to_u256(edge)
+    av = O.u256_to_ints(a)
+    for sv in edge + [int(O.u256_to_ints(rnd(6, 1))[0])]:
+        sc = O.ints_to_u256([sv])
+        for op, f in (("add", S.share_add_scalar), ("sub", S.share_sub_scalar), ("mul", S.share_mul_scalar)):
+            rc, got = e.fr_op_scalar(op, a, sc)
+            assert rc == 0 and O.u256_to_ints(got) == [f(S.Share(v, 3, 2), sv).v % R for v in av], (op, sv)
+        rc, got = e.fr_op_scalar("rsub", a, sc)
+        assert rc == 0 and O.u256_to_ints(got) == [S.share_from_scalar_sub(sv, S.Share(v, 3, 2)).v % R for v in av], sv
+    rc, _ = e.fr_op_scalar("add", a, O.ints_to_u256([R]))      # not canonical
+    assert rc == 4
+
+
 EVAL_SHAPES = [(1, 0), (2, 0), (2, 1), (3, 0), (3, 2), (4, 1), (4, 3), (5, 1), (7, 2), (8, 7), (10, 3), (13, 4), (16, 0),
                (16, 5), (16, 10), (16, 15), (9, 8), (20, 6), (31, 10), (31, 20), (31, 30), (32, 31), (33, 5), (64, 21),
                (100, 31), (100, 33), (128, 15), (255, 31), (255, 84), (200, 3)]
