@@ -91,7 +91,8 @@ def test_scalar_ops(eng_all):
     assert rc == 4
 
 
-EVAL_SHAPES = [(1, 0), (2, 0), (2, 1), (3, 0), (3, 2), (4, 1), (4, 3), (5, 1), (7, 2), (8, 7), (10, 3), (13, 4), (16, 0),
+# (5, 1), (10, 3), (20, 6): the (n, t) of the reference's own benches (mpc/benches/hmpc_mul_micro_bench.rs:37)
+EVAL_SHAPES = [(5, 1), (1, 0), (2, 0), (2, 1), (3, 0), (3, 2), (4, 1), (4, 3), (5, 1), (7, 2), (8, 7), (10, 3), (13, 4), (16, 0),
                (16, 5), (16, 10), (16, 15), (9, 8), (20, 6), (31, 10), (31, 20), (31, 30), (32, 31), (33, 5), (64, 21),
                (100, 31), (100, 33), (128, 15), (255, 31), (255, 84), (200, 3)]
 
@@ -174,7 +175,7 @@ def test_batch_recover_vs_oracle(eng, n, t, d, G, frac, max_bad):
     assert GU.eq(co[ok], x[ok])  # recovered coefficients == the original secrets
 
 
-@pytest.mark.parametrize("n,t,d", [(10, 3, 3), (16, 5, 10), (31, 10, 10)])
+@pytest.mark.parametrize("n,t,d", [(10, 3, 3), (16, 5, 10), (31, 10, 10), (5, 1, 1), (20, 6, 6)])
 def test_batch_recover_other_impls(eng_all, n, t, d):
     x, ids, ev = _corrupt_case(n, t, d, 300, 5 + n, 0.05, t)
     rc0, co0, nco0, st0 = O.batch_recover(ids, ev, n, d, t)
