@@ -438,9 +438,16 @@ def extra_measurements(eng, torch, dev, stream):
     are repaired); parity with the oracle is the test suite's job."""
     res = {}
 
-    def ev_time(fn, reps=10, warm=2):
+    def ev_time(fn, reps=10, warm=2, warm_seconds=0.15):
+        # warm up by TIME as well as by count: these rows run after seconds of CPU-only work (the cpu_baseline legs),
+        # i.e. on an idle chip at low clocks, which two launches do not bring back
+        t_w = time.perf_counter()
         for _ in range(warm):
             fn()
+        torch.cuda.synchronize()
+        while time.perf_counter() - t_w < warm_seconds:
+            fn()
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

@@ -208,7 +208,10 @@ struct MfmaRowsArgs {
                           // 2 = no MFMAs, 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored
 };
 
-template <int M, int CG, int WAVES>
+// NR > 0: every role of the launch has at most NR rows and the row loop is unrolled NR times with a compile-time trip
+// count -- hipcc can then count the stores issued after the next tile's loads and wait with vmcnt(#stores) at the tile
+// boundary; with a run-time trip count it waits for vmcnt(0), i.e. for every store of the tile to complete.
+template <int M, int CG, int WAVES, int NR = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     static_assert(M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp) and the sum below 2^273");
     constexpr int ROWB = M * 1024 + 128;
@@ -274,7 +277,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
             for (int i = 0; i < M; ++i) data[cg][i] = flip(data[cg][i]);
         }
         auto load_ys = [&](int r, v4i (&ys)[CG]) {  // claimed values of verify row r (table row index)
-            const uint8_t* base = a.in + (size_t)a.rows[M + r] * a.row_stride * 32;
+            uint32_t ri = (uint32_t)a.rows[M + r];
+            asm volatile("" : "+s"(ri));  // recomputed at every use: hoisted out of the tile loop, the row bases of an
+                                          // unrolled row loop (NR > 0) would take two SGPRs each and spill the scalar file
+            const uint8_t* base = a.in + (size_t)ri * a.row_stride * 32;
 #pragma unroll
             for (int cg = 0; cg < CG; ++cg) ys[cg] = *reinterpret_cast<const v4i*>(base + (g[cg] * 32u + 16u * h));
         };
@@ -283,7 +289,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
         uint32_t bad[CG];
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) bad[cg] = 0;
-        for (int r = 0; r < role.nrows; ++r) {
+#pragma unroll
+        for (int r = 0; r < (NR > 0 ? NR : role.nrows); ++r) {
+            if (NR > 0 && r >= role.nrows) break;
             const uint8_t* cur = lds + (size_t)r * ROWB;
             const int rho = role.row0 + r;
             if (r + 1 < nver) load_ys(rho + 1, ys_next);
@@ -309,7 +317,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                     for (int cg = 0; cg < CG; ++cg) ys_cur[cg] = ys_next[cg];
                 }
             } else {
-                const size_t k = (size_t)(rho - a.nv);
+                uint32_t k32 = (uint32_t)(rho - a.nv);
+                asm volatile("" : "+s"(k32));  // as above: the output row base is recomputed, not kept per unrolled row
+                const size_t k = k32;
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
                     uint32_t Rw[4];

@@ -193,3 +193,62 @@ def test_gather_party_major_two_contexts():
     finally:
         e0.close()
         e1.close()
+
+
+ENC_SHAPES = [(31, 10), (20, 6), (17, 1), (33, 5), (64, 14), (100, 9), (255, 14), (31, 13), (40, 3)]
+
+
+@pytest.mark.parametrize("n,d", ENC_SHAPES)
+@pytest.mark.parametrize("wgs", [0, 8])
+def test_encode_vs_oracle(eng, n, d, wgs):
+    """apply_vandermonde / compute_shares on the matrix cores (domains beyond 16 points, 2 <= d + 1 <= 15): against the
+    oracle and against the FFT kernels, edge polynomials included; wgs = 8 walks both input register sets"""
+    G = 1200 + 41 if wgs == 0 else 7000 + 3
+    eng.set_matrix_core_workgroups(wgs)
+    try:
+        x = rnd(50 + n + d, G, d + 1)
+        x[0] = 0
+        x[1] = O.ints_to_u256([O_R - 1] * (d + 1))
+        x[2, :, :] = 0
+        x[2, d, 0] = 1
+        eng.set_matrix_cores(True, 1)
+        rc, y = eng.vandermonde_apply(x, n, d)
+        rc2, y2 = eng.compute_shares(x, n, d)
+        eng.set_matrix_cores(False)
+        rc1, y1 = eng.vandermonde_apply(x, n, d)
+        eng.set_matrix_cores(True, 65536)
+        rc0, y0 = O.vandermonde_apply(x, n, d)
+        assert rc == rc0 == rc1 == rc2 == 0 and np.array_equal(y, y0) and np.array_equal(y1, y0) and np.array_equal(y2, y0)
+    finally:
+        eng.set_matrix_core_workgroups(0)
+        eng.set_matrix_cores(True, 65536)
+
+
+def test_full_size_config3_encode(eng):
+    """BASELINE configs[2]'s encode: x[2^20][11] -> y[31][2^20], matrix cores against the FFT kernels (whole array) and
+    against the oracle (sampled chunks); strided output rows (the in-place wire path) as well"""
+    import torch
+    n, d, G = 31, 10, 1 << 20
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC0FFEE06)
+    lo = torch.randint(0, 1 << 62, (G, d + 1, 3), dtype=torch.int64, device=dev, generator=gen)
+    hi = torch.randint(0, 0x73EDA753299D7D48, (G, d + 1, 1), dtype=torch.int64, device=dev, generator=gen)
+    x = torch.cat([lo, hi], dim=-1).contiguous()
+    ys = {}
+    for mode in ("mfma", "fft"):
+        eng.set_matrix_cores(mode == "mfma", 65536)
+        y = torch.full((n, G, 4), -1, dtype=torch.int64, device=dev)
+        ystr = torch.full((n, G + 8, 4), -1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        assert eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), 0) == 0
+        assert eng.dev_vandermonde_apply_strided(x.data_ptr(), G, n, d, ystr.data_ptr(), G + 8, 0) == 0
+        eng.sync()
+        ys[mode] = (y, ystr)
+    eng.set_matrix_cores(True, 65536)
+    assert torch.equal(ys["mfma"][0], ys["fft"][0]) and torch.equal(ys["mfma"][1], ys["fft"][1])
+    assert torch.equal(ys["mfma"][1][:, :G], ys["mfma"][0]) and bool((ys["mfma"][1][:, G:] == -1).all())
+    idx = np.unique(np.concatenate([np.arange(0, 70), np.arange(G - 70, G), np.arange(31, G, 32)[:40], np.arange(32 * 3072 - 3, 32 * 3072 + 3)]))
+    ti = torch.as_tensor(idx, device=dev)
+    rc0, y0 = O.vandermonde_apply(np.ascontiguousarray(x[ti].cpu().numpy().view(np.uint64)), n, d)
+    assert rc0 == 0 and np.array_equal(ys["mfma"][0][:, ti].cpu().numpy().view(np.uint64), y0)

@@ -53,7 +53,7 @@ static float time_ms(F f, int reps) {
 }
 
 static int g_nwg = 256;  // workgroups per launch (one per CU: the table rows of a role fill most of the LDS)
-template <int M, int CG, int WAVES>
+template <int M, int CG, int WAVES, int NR = 0>
 static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     constexpr int ROWB = M * 1024 + 128;
     const int cap = (160 * 1024) / ROWB;
@@ -73,10 +73,14 @@ static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    if (NR > 0 && mf::mf_max_role_rows(a) > NR) {
+        fprintf(stderr, "role rows %d exceed the static row count %d\n", mf::mf_max_role_rows(a), NR);
+        exit(2);
+    }
+    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES, NR>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 // encode x[G][M] with [I ; Cv] -> evals[M + nv][G]; decode with verify rows Cv and output rows Co; check vs host
@@ -153,6 +157,17 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
                         (unsigned long long)yrow[0], (unsigned long long)want[0]);
         }
     }
+    if (nv > 14) {
+        // encode only (e.g. 31 rows = config 3's apply_vandermonde): more verify rows than one decode role holds
+        const float ms_e = time_ms([&] { launch_rows<M, CG, WAVES>(ea, n); }, reps);
+        const float ms_s = time_ms([&] { launch_rows<M, CG, WAVES, 11>(ea, n); }, reps);
+        printf("{\"shape\": \"%s\", \"M\": %d, \"CG\": %d, \"waves\": %d, \"chunks\": %zu, \"errors\": %d, \"encode_%d_rows_ms\": %.4f, "
+               "\"encode_%d_rows_static_row_count_ms\": %.4f, \"encode_GBps\": %.0f}\n", name, M, CG, WAVES, G, errors, n, ms_e, n, ms_s,
+               (double)(M + n) * 32 * G / (ms_s < ms_e ? ms_s : ms_e) / 1e6);
+        fflush(stdout);
+        for (void* q : {(void*)d_tenc, (void*)d_tdec, (void*)d_tp0, (void*)d_x, (void*)d_y, (void*)d_out, (void*)d_st, (void*)d_flag, (void*)d_cnt, (void*)d_sum}) (void)hipFree(q);
+        return errors;
+    }
     // corrupt two chunks: one in a verify row, one in an interpolation row
     const size_t bad1 = G / 3, bad2 = G / 2 + 1;
     {
@@ -202,6 +217,10 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
     CK(hipDeviceSynchronize());
     const float ms_enc = time_ms([&] { launch_rows<M, CG, WAVES>(ea, n); }, reps);
     const float ms_dec = time_ms([&] { launch_rows<M, CG, WAVES>(ra, nv + M); }, reps);
+    // the same launches with a compile-time row count (16 covers every role of these shapes)
+    const float ms_enc_s = time_ms([&] { launch_rows<M, CG, WAVES, (M == 11 ? 11 : 16)>(ea, n); }, reps);
+    const float ms_dec_s = time_ms([&] { launch_rows<M, CG, WAVES, (M == 11 ? 11 : 16)>(ra, nv + M); }, reps);
+    fprintf(stderr, "   static row count: encode %.4f -> %.4f ms, decode %.4f -> %.4f ms\n", ms_enc, ms_enc_s, ms_dec, ms_dec_s);
     mf::MfmaRowsArgs rp = ra;
     rp.table = d_tp0, rp.out_stride = 1;
     const float ms_p0 = time_ms([&] { launch_rows<M, CG, WAVES>(rp, nv + 1); }, reps);
@@ -235,7 +254,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
     const size_t G = (size_t)1 << lg;
     int errors = 0;
-    const int mask = argc > 3 ? atoi(argv[3]) : 0x7f;
+    const int mask = argc > 3 ? atoi(argv[3]) : 0xff;
     // ragged small case first (live masks, partial tiles)
     if (argc > 4) g_nwg = atoi(argv[4]);
     if (mask & 1) errors += run_shape<11, 2, 8>("cfg3_ragged", 10, 1000 + 37, 2);
@@ -244,6 +263,7 @@ int main(int argc, char** argv) {
     if (mask & 4) errors += run_shape<11, 1, 12>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
     if (mask & 8) errors += run_shape<11, 1, 16>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
     if (mask & 16) errors += run_shape<11, 2, 8>("cfg3 n=31 t=10 (decode: 21 of the rows)", 10, G, reps);
+    if (mask & 128) errors += run_shape<11, 1, 12>("cfg3 encode: apply_vandermonde n=31 d=10 (31 rows)", 20, G, reps);
     if (mask & 32) errors += run_shape<6, 1, 16>("cfg2-like m=6, 10 extra rows", 10, G, reps);
     if (mask & 64) errors += run_shape<6, 2, 8>("cfg2-like m=6, 10 extra rows", 10, G, reps);
     fprintf(stderr, errors ? "FAILED: %d errors\n" : "all checks passed\n", errors);
