@@ -177,6 +177,12 @@ ShareErrorCode hbmpc_dev_compute_shares(hbmpc_ctx* ctx, const U256* coeffs_dev, 
  * ark_std/rand generator, robust_interpolate.rs:66-67): a deployment that needs bit-equality with a given Rust rng
  * keeps drawing on the host and calls hbmpc_compute_shares.  first_index lets a dealer split one seed over several
  * calls / GPUs without reusing stream positions (rank r of W deals indices [r B, (r+1) B)).
+ * SECURITY: the pair (seed, polynomial index) fixes the random coefficients.  Two calls that use the same seed and
+ * overlapping index ranges for DIFFERENT secrets produce sharings with identical higher coefficients, so every party
+ * learns share_i(s1) - share_i(s2) = s1 - s2.  Nothing in the library can detect that: the caller must never reuse an
+ * index under one seed (take first_index from a counter that only grows, as rust/gpu_shares.rs does, or derive a fresh
+ * seed per call).  The coefficient workspace and the library's staging buffers hold secret polynomial coefficients
+ * and are recycled without being cleared: clear the workspace yourself if the threat model asks for it.
  * secrets (host or device) may be NULL: the secret of every polynomial is then drawn as well, as coefficient k = 0
  * of the same stream -- the dealer loop of RanSha (share_gen/share_gen.rs:249-256: `F::rand(rng)` followed by
  * compute_shares) without a host rng; the secrets are column 0 of the workspace.

@@ -715,6 +715,9 @@ extern "C" ShareErrorCode hbmpc_set_small_call_staging(hbmpc_ctx* ctx, int zero_
 static ShareErrorCode eval_host(hbmpc_ctx* ctx, const void* x, size_t G, size_t n, size_t d, void* y) {
     if (!ctx) return InvalidInput;
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
+    // the range checks of eval_dev, before any size arithmetic with n and d
+    if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
+    if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
     if (G == 0) return ShareSuccess;
     if (!x || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
