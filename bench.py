@@ -167,6 +167,11 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-final-gather", action="store_true",
                     help="N > 1: skip the all-gather of the shares after the timed region (the path's only collective)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the barrier / max-reduce / final gather (nccl = RCCL; gloo: rehearsal of "
+                         "the N > 1 control flow where RCCL cannot run, e.g. several ranks on one GPU with --same-device)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (with --dist-backend gloo); the numbers then mean nothing")
     ap.add_argument("--impl", default="u29", choices=["u29", "sat32"])
     ap.add_argument("--recon-kernels", default="mfma", choices=["mfma", "lane"],
                     help="batch_recover on the matrix cores (default) or with the lane-per-chunk kernels (A/B)")
@@ -182,11 +187,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from __graft_entry__ import load_package
     pkg = load_package()
@@ -208,7 +218,7 @@ def main():
     def max_reduce(x):
         if world == 1:
             return x
-        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        tt = torch.tensor([x], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
@@ -221,6 +231,8 @@ def main():
         out = bench_metric(ctx)
     else:
         out = bench_pipeline(ctx)
+    if args.same_device:
+        out["rehearsal"] = "all ranks on GPU 0 over gloo: a check of the N > 1 control flow, not a measurement"
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
