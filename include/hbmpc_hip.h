@@ -304,6 +304,16 @@ ShareErrorCode hbmpc_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U25
 ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open,
                                       size_t m, size_t N, U256* d_out);
 
+/* TripleGenNode::init_batch for `parties` simulated parties in one launch: [ab - r]_2t = a_i b_i - r2t_i per element
+ * (triple_gen/triple_generation.rs:333-340) followed by the BatchRecon encode of the chunks of d + 1 = 2t + 1 values
+ * (batch_recon/batch_recon.rs:157-165): a, b, r2t are [parties][G (d+1)], y_out is [parties][n][G] exactly as
+ * hbmpc_dev_vandermonde_apply_parties writes it.  Where a fused kernel exists (bls12-381 Fr, domains up to 16 points,
+ * d + 1 in {3, 5, 7, 9, 11}) the local products never touch HBM; other shapes run the two launches through tmp_dev
+ * (parties G (d+1) elements; may be NULL only when the fused kernel applies -- InvalidInput otherwise).  Results are
+ * those of hbmpc_dev_triple_local followed by hbmpc_dev_vandermonde_apply_parties, bit for bit. */
+ShareErrorCode hbmpc_dev_triple_encode_parties(hbmpc_ctx* ctx, const U256* a_dev, const U256* b_dev, const U256* r2t_dev,
+                                               size_t G, size_t n, size_t d, size_t parties, U256* tmp_dev, U256* y_out_dev,
+                                               void* stream);
 ShareErrorCode hbmpc_dev_triple_local(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, size_t N,
                                       U256* out, void* stream);
 ShareErrorCode hbmpc_dev_triple_finalize(hbmpc_ctx* ctx, const U256* rt, const U256* opened, size_t N, U256* c_out,
@@ -469,6 +479,9 @@ ShareErrorCode hbmpc_gl_dev_fr_op(hbmpc_ctx* ctx, int op, const uint64_t* a, con
                                   void* stream);
 ShareErrorCode hbmpc_gl_triple_local(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, size_t N,
                                      uint64_t* out);
+ShareErrorCode hbmpc_gl_dev_triple_encode_parties(hbmpc_ctx* ctx, const uint64_t* a_dev, const uint64_t* b_dev,
+                                                  const uint64_t* r2t_dev, size_t G, size_t n, size_t d, size_t parties,
+                                                  uint64_t* tmp_dev, uint64_t* y_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_triple_local(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, size_t N,
                                          uint64_t* out, void* stream);
 ShareErrorCode hbmpc_gl_triple_finalize(hbmpc_ctx* ctx, const uint64_t* rt, const uint64_t* opened, size_t N, uint64_t* c_out);

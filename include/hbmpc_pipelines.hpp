@@ -114,12 +114,10 @@ class TripleGen : public CapturablePipeline {
     }
     void run() override {
         const size_t n = n_, N = N_, G = G_, d = 2 * t_;
-        // [ab - r]_2t = a_i b_i - r2t_i  (triple_generation.rs:333-340), into c as scratch: the [party][N] arrays are
-        // contiguous, so one launch over n N elements serves all parties
-        pl_check(hbmpc_dev_triple_local(ctx_, a, b, r2t, n * N, c, stream_), ctx_, "triple_local");
-        // Vandermonde-encode the chunks of 2t+1 for every recipient (batch_recon.rs:157-165): c[party][G][2t+1] ->
-        // Y[party][n][G], all parties in one launch
-        pl_check(hbmpc_dev_vandermonde_apply_parties(ctx_, c, G, n, d, n, Y_, stream_), ctx_, "encode");
+        // [ab - r]_2t = a_i b_i - r2t_i (triple_generation.rs:333-340) Vandermonde-encoded in chunks of 2t+1 for every
+        // recipient (batch_recon.rs:157-165): a, b, r2t [party][N] -> Y[party][n][G], all parties in ONE launch; the local
+        // products stay on chip where the fused kernel covers the shape (c is the workspace of the two-launch path)
+        pl_check(hbmpc_dev_triple_encode_parties(ctx_, a, b, r2t, G, n, d, n, c, Y_, stream_), ctx_, "local product + encode");
         // EvalBatch arm for ALL recipients in one call: with Y[p][j][g] the row of sender p for "chunk" j G + g is
         // Y + p (n G) + (j G + g), and the output is already Z[j][g]
         pl_check(hbmpc_dev_batch_recover_strided(ctx_, ids_.data(), n, Y_, n * G, n * G, n, d, t_, 1, Z_, nullptr, status_, summ,

@@ -958,6 +958,35 @@ static ShareErrorCode triple_local_any(hbmpc_ctx* ctx, const void* a, const void
     BY_FIELD(k_triple_local, W(a), W(b), W(r2t), N, cs, WO(out));
     return ShareSuccess;
 }
+// TripleGenNode::init_batch for `parties` parties at once: x = a b - r2t per element, then the Vandermonde encode of the
+// chunks of d + 1 -- one launch where k_eval_fft1_triple covers the shape, otherwise the two separate ones through `tmp`
+static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const void* b, const void* r2t, size_t G, size_t n, size_t d,
+                                        size_t parties, void* tmp, void* y, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (parties == 0 || parties > 65535) return fail(ctx, InvalidInput, "parties must be in 1..65535");
+    if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
+    if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
+    if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
+    if (G == 0) return ShareSuccess;
+    if (!a || !b || !r2t || !y) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    const size_t size = domain_size(n), dp1 = d + 1;
+    if (ctx->impl == IMPL_U29 && size <= 16 && !ctx->force_generic) {
+        const uint32_t* tw;
+        ShareErrorCode rc = get_table(ctx, key("tw", {size}, ctx->impl), [&] { return build_twiddles<HFr>(size, ctx->impl); }, &tw);
+        if (rc != ShareSuccess) return rc;
+        const ElemConsts cs = elem_consts(ctx->impl);
+        if (launch_fft1_triple(ilog2(size), (int)dp1, W(a), W(b), W(r2t), G, (int)n, tw, EvalOut{WO(y), 0, (unsigned)parties}, cs.r2, s)) {
+            HIP_TRY(ctx, hipGetLastError());
+            return ShareSuccess;
+        }
+    }
+    if (!tmp) return fail(ctx, InvalidInput, "no fused kernel for this shape: pass a workspace of parties * G * (d + 1) elements");
+    ShareErrorCode rc = triple_local_any(ctx, a, b, r2t, parties * G * dp1, tmp, stream);
+    if (rc != ShareSuccess) return rc;
+    return eval_dev(ctx, tmp, G, n, d, y, stream, parties);
+}
 static ShareErrorCode triple_finalize_any(hbmpc_ctx* ctx, const void* rt, const void* opened, size_t N, void* c_out,
                                           void* stream, size_t parties = 1) {
     ELEM_PROLOGUE
@@ -989,6 +1018,12 @@ static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const v
                                                     T* out, void* stream) {                                              \
         REQ(ctx);                                                                                                        \
         return fr_op_scalar_any(ctx, op, a, scalar_host, N, out, stream);                                                \
+    }                                                                                                                    \
+    extern "C" ShareErrorCode PFX##dev_triple_encode_parties(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t,       \
+                                                             size_t G, size_t n, size_t d, size_t parties, T* tmp,        \
+                                                             T* y_out, void* stream) {                                   \
+        REQ(ctx);                                                                                                        \
+        return triple_encode_any(ctx, a, b, r2t, G, n, d, parties, tmp, y_out, stream);                                  \
     }                                                                                                                    \
     extern "C" ShareErrorCode PFX##dev_triple_local(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t, size_t N,      \
                                                     T* out, void* stream) {                                              \

@@ -281,6 +281,55 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
 }
 
 // ---------------------------------------------------------------------------------------------
+// TripleGenNode::init_batch in ONE kernel (triple_gen/triple_generation.rs:333-340 followed by the BatchRecon encode,
+// batch_recon/batch_recon.rs:157-165): the chunk values x[g][k] = a b - r2t are computed while the tile is staged, so
+// the [party][N] array of local products is never written to HBM and read back (config 4: 4.4 of 22 GB per step).
+// a, b, r2t: [party][G * CNT] canonical, the flat element order of the chunks; one lane per element while staging.
+// ---------------------------------------------------------------------------------------------
+struct TripleConsts {
+    uint32_t r2[9];  // R^2 mod r in device-constant form (ElemConsts::r2)
+};
+template <class F, int LOG, int CNT>
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves_min<LOG, CNT>(), F::template eval_waves<LOG, CNT>()))) void k_eval_fft1_triple(
+    const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ r2t, size_t G, int n,
+    const uint32_t* __restrict__ tw, uint32_t* __restrict__ y, size_t ys, TripleConsts cs) {
+    using E = typename F::E;
+    constexpr int S = 1 << LOG;
+    static_assert(CNT <= S && fft_max_vb<LOG, CNT, 1, 1>() <= 64, "bounds");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * EVAL_TILE;
+    const size_t poff = (size_t)blockIdx.y * G * CNT * F::EW;  // blockIdx.y = party
+    a += poff, b += poff, r2t += poff;
+    y += (size_t)blockIdx.y * n * ys * F::EW;
+    {
+        const size_t rows = G - g0 < (size_t)EVAL_TILE ? G - g0 : (size_t)EVAL_TILE;
+        const int total = (int)rows * CNT, pitch = tile_pitch_words<F::EW>(CNT);
+        const size_t e0 = g0 * CNT;
+#pragma unroll
+        for (int it = 0; it < CNT; ++it) {  // rows * CNT elements, 64 per trip: CNT trips
+            const int p = it * EVAL_TILE + lane;
+            const int pc = p < total ? p : total - 1;  // clamped: lanes past the end redo the last element
+            const E am = F::mulc(F::load(a + (e0 + pc) * F::EW), cs.r2);
+            const E pr = F::mont(F::load(b + (e0 + pc) * F::EW), am);  // a b, < 2r
+            const E c = F::template sub<2>(pr, F::load(r2t + (e0 + pc) * F::EW));
+            const int row = pc / CNT, k = pc - row * CNT;
+            F::store_loose(lds + row * pitch + k * F::EW, c);
+        }
+    }
+    __syncthreads();
+    const size_t g = g0 + lane;
+    if (g >= G) return;
+    const uint32_t* row = lds + lane * tile_pitch_words<F::EW>(CNT);
+    E X[S];
+    load_plain<F, LOG, CNT>(X, row, CNT, false, std::make_integer_sequence<int, S>{});
+    fft_pruned_sink<F, LOG, CNT, 1, 1>(X, tw, [&](auto idx, const E& v) {
+        constexpr int j = decltype(idx)::value;
+        if (j < n) F::store_loose(y + ((size_t)j * ys + g) * F::EW, v);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
 // multi-pass kernel: size = 16 * P (P = 2, 4, 8, 16), DP1 <= 32 coefficients.
 // twist[r][k] = omega_size^(r k) (device-constant form), r < P, k < dp1 (row r = 0 unused).
 // CNT16 = min(dp1, 16).  FOLD = dp1 > 16.

@@ -204,7 +204,7 @@ struct MfmaRowsArgs {
     int role_nwg[MF_MAX_ROLES];
     uint8_t blk_role[64], blk_idx[64];
     MfmaRole role[MF_MAX_ROLES];
-    int abl;              // microbenchmark ablations (tools/ubench_mfma.hip), 0 in the library: 1 = no epilogue arithmetic,
+    int abl;              // microbenchmark ablations (tools/ubench_mfma.hip), 0 in the library: 1 = no epilogue arithmetic (loads and stores stay),
                           // 2 = no MFMAs, 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored
 };
 
@@ -306,9 +306,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                 for (int cg = 0; cg < CG; ++cg) acc[cg] = bias;
                 if (!(a.abl & 2)) mfma_row<M, CG>(cur + lane * 16, data, acc);
             }
-            if (a.abl & 1) {
+            if ((a.abl & 1) && r < nver) {
 #pragma unroll
-                for (int cg = 0; cg < CG; ++cg) bad[cg] |= (uint32_t)acc[cg][0] & (uint32_t)acc[cg][7] & 0x80000000u;  // digit sums are < 2^24
+                for (int cg = 0; cg < CG; ++cg) bad[cg] |= (uint32_t)acc[cg][0] & (uint32_t)acc[cg][7] & (uint32_t)ys_cur[cg][0] & 0x80000000u;  // digit sums are < 2^24
+                if (r + 1 < nver) {
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) ys_cur[cg] = ys_next[cg];
+                }
             } else if (r < nver) {
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) bad[cg] |= verify_tile(acc[cg], ys_cur[cg], H) & (a.abl ? 0u : ~0u);
@@ -323,7 +327,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
                     uint32_t Rw[4];
-                    reduce_tile(acc[cg], Rw, H);
+                    if (a.abl & 1) Rw[0] = acc[cg][0], Rw[1] = acc[cg][5], Rw[2] = acc[cg][10], Rw[3] = acc[cg][15];  // no arithmetic, same stores
+                    else reduce_tile(acc[cg], Rw, H);
                     uint8_t* qb = a.out_party_major ? a.out + k * a.out_stride * 32 : a.out + k * 32;  // wave-uniform
                     const uint32_t qo = g[cg] * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
                     if (live[cg] && (!(a.abl & 4) || Rw[0] == 0x12345u)) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);

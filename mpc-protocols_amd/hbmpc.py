@@ -375,6 +375,11 @@ class Engine:
         return self._f("dev_vandermonde_apply")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),
                                                   C.c_size_t(d), C.c_void_p(y_d), C.c_void_p(stream))
 
+    def dev_triple_encode_parties(self, a_d, b_d, r2t_d, G, n, d, parties, tmp_d, y_d, stream=0):
+        return self._f("dev_triple_encode_parties")(self.ctx, C.c_void_p(a_d), C.c_void_p(b_d), C.c_void_p(r2t_d), C.c_size_t(G),
+                                                      C.c_size_t(n), C.c_size_t(d), C.c_size_t(parties), C.c_void_p(tmp_d),
+                                                      C.c_void_p(y_d), C.c_void_p(stream))
+
     def dev_vandermonde_apply_parties(self, x_d, G, n, d, parties, y_d, stream=0):
         return self._f("dev_vandermonde_apply_parties")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
                                                         C.c_size_t(parties), C.c_void_p(y_d), C.c_void_p(stream))

@@ -101,12 +101,10 @@ class TripleGen(_Capturable):
         e, n, t, N, G, m, s = self.eng, self.n, self.t, self.N, self.G, self.m, self.stream
         d = 2 * t
         ids = list(range(n))
-        # 1. every party: [ab - r]_2t = a_i * b_i - r2t_i   (triple_generation.rs:333-340), into c as scratch; the
-        #    [party][N] arrays are contiguous, so ONE launch over n N elements serves all parties
-        _check(e.dev_elem("triple_local", [self.a, self.b, self.r2t, self.c], n * N, stream=s), e, "triple_local")
-        # 2. every party: Vandermonde-encode its chunks of 2t+1 -> y for each recipient (batch_recon.rs:157-165)
-        #    c[party][G][2t+1] -> Y[party][n][G], all parties in one launch
-        _check(e.dev_vandermonde_apply_parties(self.c, G, n, d, n, self.Y, s), e, "encode")
+        # 1 + 2. every party: [ab - r]_2t = a_i * b_i - r2t_i (triple_generation.rs:333-340), Vandermonde-encoded in chunks of
+        #    2t+1 -> y for each recipient (batch_recon.rs:157-165): Y[party][n][G], ONE launch for all parties -- the local
+        #    products never touch HBM where the fused kernel covers the shape (c is the workspace of the two-launch path)
+        _check(e.dev_triple_encode_parties(self.a, self.b, self.r2t, G, n, d, n, self.c, self.Y, s), e, "local product + encode")
         # 3. EvalBatch arm: recipient j interpolates its y_j from the senders' evaluations (needs d+t+1 = 3t+1).
         #    With Y[p][j][g] the row of sender p for "chunk" c = j G + g is Y + p (n G) + c: ONE strided decode over
         #    n G chunks is all n recipients at once, and its output Z[c] is already Z[j][g].

@@ -126,3 +126,37 @@ def test_fpmul_pipeline_as_hip_graph(pkg_eng):
         fp.replay()
         assert GU.eq(fp.download("out"), want), seed
     fp.close()
+
+
+@pytest.mark.parametrize("n,t,G,parties", [(4, 1, 77, 4), (7, 2, 130, 7), (10, 3, 65, 3), (13, 4, 200, 13), (16, 5, 333, 16),
+                                           (16, 5, 64, 1), (8, 1, 50, 2), (20, 6, 40, 3), (5, 1, 10, 5)])
+def test_triple_encode_fused_equals_two_launches(pkg_eng, n, t, G, parties):
+    """hbmpc_dev_triple_encode_parties (local product fused into the encode where a kernel exists; (20, 6) has none and
+    takes the workspace path) against hbmpc_dev_triple_local + hbmpc_dev_vandermonde_apply_parties, and the first party
+    against the oracle"""
+    import torch
+    pkg, eng = pkg_eng
+    d = 2 * t
+    N = G * (d + 1)
+    dev = torch.device("cuda", 0)
+    a, b, r = (torch.from_numpy(O.fill_random(60 + k, parties * N).view(np.int64)).to(dev) for k in range(3))
+    tmp = torch.empty((parties * N, 4), dtype=torch.int64, device=dev)
+    y1 = torch.full((parties, n, G, 4), -1, dtype=torch.int64, device=dev)
+    y2 = torch.full((parties, n, G, 4), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, tmp.data_ptr(), y1.data_ptr()) == 0
+    assert eng.dev_elem("triple_local", [a.data_ptr(), b.data_ptr(), r.data_ptr(), tmp.data_ptr()], parties * N) == 0
+    assert eng.dev_vandermonde_apply_parties(tmp.data_ptr(), G, n, d, parties, y2.data_ptr()) == 0
+    eng.sync()
+    assert torch.equal(y1, y2)
+    ah, bh, rh = (v[:N].cpu().numpy().view(np.uint64) for v in (a, b, r))
+    x = O.triple_local(ah, bh, rh)[1].reshape(G, d + 1, 4)
+    rc, want = O.vandermonde_apply(x, n, d)
+    assert rc == 0 and np.array_equal(y1[0].cpu().numpy().view(np.uint64), want)
+    if n <= 16 and d + 1 in (3, 5, 7, 9, 11):   # the fused kernel needs no workspace
+        y3 = torch.full_like(y1, -1)
+        assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, 0, y3.data_ptr()) == 0
+        eng.sync()
+        assert torch.equal(y3, y1)
+    else:
+        assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, 0, y1.data_ptr()) == 4

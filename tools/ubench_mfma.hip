@@ -227,12 +227,19 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
     CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
     if (G > 100000) {
         fprintf(stderr, "   ablation %s CG=%d waves=%d: full %.4f ms", name, CG, WAVES, ms_dec);
-        for (int abl : {1, 2, 4, 5, 6, 7}) {
+        for (int abl : {1, 2, 3, 4, 5, 6, 7}) {
             mf::MfmaRowsArgs rb = ra;
             rb.abl = abl;
             fprintf(stderr, " | abl %d: %.4f", abl, time_ms([&] { launch_rows<M, CG, WAVES>(rb, nv + M); }, reps));
         }
-        fprintf(stderr, "   (1 = no epilogue, 2 = no MFMA, 4 = inputs from L2 + no stores)\n");
+        fprintf(stderr, "   (1 = no epilogue arithmetic, 2 = no MFMA, 3 = memory traffic only, 4 = inputs from L2 + no stores)\n");
+        fprintf(stderr, "   encode ablation %s CG=%d waves=%d: full %.4f ms", name, CG, WAVES, ms_enc);
+        for (int abl : {1, 2, 3, 4, 5, 6, 7}) {
+            mf::MfmaRowsArgs eb = ea;
+            eb.abl = abl;
+            fprintf(stderr, " | abl %d: %.4f", abl, time_ms([&] { launch_rows<M, CG, WAVES>(eb, n); }, reps));
+        }
+        fprintf(stderr, "\n");
         CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
     }
     if (cnt[0] != 0) {
