@@ -510,8 +510,13 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * vector (a function of n, d, t and the sender ids) times batch data, i.e. an int8 GEMM over the bytes of the canonical
  * elements followed by one carry pass and one small-quotient reduction (csrc/kernels_mfma.hpp).  Results are
  * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both).
- * min_chunks = 0 keeps the current threshold (default 65536: a sender set not seen before costs ~1 ms of host
- * table construction). */
+ * min_chunks = 0 keeps the current thresholds.  Defaults: a decode of >= 65 536 chunks always takes the path (a sender
+ * set not seen before costs ~0.7 ms of host table construction, more than a smaller call saves); a decode of
+ * 6 144 .. 65 535 chunks takes it when the sender set's table is already cached, and builds it the SECOND time the
+ * set is seen (a set seen once stays with the lane kernels); evaluations on domains beyond 16 points (one table per
+ * (n, d), never rebuilt) take it from 4 096 chunks.  A nonzero min_chunks sets the first threshold and caps the other
+ * two at it -- e.g. (1, 6144) before the eager run that precedes a graph capture makes mid-size decodes build their
+ * table at once (nothing can be built during capture: a call whose table is missing then records the lane kernels). */
 ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);
 /* test aid: workgroups of a matrix-core launch (0 = one per CU, the default); a small number makes a small batch walk
  * the multi-tile loop of every wave */

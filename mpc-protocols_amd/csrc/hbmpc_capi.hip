@@ -51,6 +51,9 @@ struct hbmpc_ctx {
     bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
     bool matrix_cores = true;                      // large Fr decodes run the int8 MFMA formulation (kernels_mfma.hpp)
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
+    size_t mfma_min_cached = 6144;                 // ... and from this many when the sender set's table is cached or the set recurs
+    size_t mfma_min_encode = 4096;                 // encodes (one table per (n, d), never rebuilt): from this many chunks
+    std::map<std::string, int> mfma_seen;          // sender sets of mid-size decodes that went to the lane kernels, by sightings
     int n_cus = 256;
     int mfma_wgs = 0;                              // test aid: workgroups of a matrix-core launch (0 = one per CU)
     std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
@@ -131,6 +134,19 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
     if (aux) tab.aux = *aux;
     *out = dev;
     return ShareSuccess;
+}
+// Is `key` cached?  If not, count the sighting and say how many there have been (the matrix-core decode builds its table
+// for a mid-size batch only when the sender set comes back: capi_recover.inc).
+static bool table_cached_or_count(hbmpc_ctx* ctx, const std::string& key, int* sightings) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->tables.find(key) != ctx->tables.end()) return true;
+    if (g_capturing) {
+        *sightings = 0;  // nothing may be built now: the call takes the kernels whose tables the eager run built
+        return false;
+    }
+    if (ctx->mfma_seen.size() >= 4096) ctx->mfma_seen.clear();
+    *sightings = ++ctx->mfma_seen[key];
+    return false;
 }
 // Per-stream scratch from plain hipMalloc.  NOT hipMallocAsync: data written to stream-ordered-pool memory by
 // one kernel was observed stale for workgroups of the NEXT kernel that run on other XCDs (their L2 kept the
@@ -251,7 +267,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
     if (!ctx) return InvalidInput;
     REQ_FR(ctx);
     ctx->matrix_cores = on != 0;
-    if (min_chunks) ctx->mfma_min_chunks = min_chunks;
+    if (min_chunks) {
+        ctx->mfma_min_chunks = min_chunks;
+        ctx->mfma_min_cached = std::min<size_t>(min_chunks, 6144);
+        ctx->mfma_min_encode = std::min<size_t>(min_chunks, 4096);
+    }
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups) {
@@ -491,7 +511,7 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
                               launch_fft1_16c(c, x, G, nn, tw, y, s) || launch_fft1_16d(c, x, G, nn, tw, y, s))))
             return ShareSuccess;
     } else if (impl == IMPL_U29 && ctx->matrix_cores && !ctx->force_generic && y.parties == 1 && dp1 >= 2 && dp1 <= MF_MAX_M &&
-               G >= ctx->mfma_min_chunks && G * dp1 * 32 < ((size_t)1 << 32) && n <= 255 &&
+               G >= ctx->mfma_min_encode && G * dp1 * 32 < ((size_t)1 << 32) && n <= 255 &&
                try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf)) {
         // domains beyond 16 points: the dense n x (d + 1) map on the matrix cores beats the multi-pass FFT (config 3's
         // encode: 0.45 ms against 0.62 ms); up to 16 points the single-pass FFT stays (config 2: a tie at 0.187 ms)
