@@ -2,6 +2,9 @@
 // directions, both directions at once, and multi-threaded CPU memcpy between pinned and pageable memory.
 //   hipcc -O2 --offload-arch=gfx950 -o /tmp/ubench_pcie tools/ubench_pcie.hip -lpthread
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
+#include <atomic>
+#include <vector>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +37,39 @@ int main() {
     }
     {   // fresh pageable destination: page faults included
         double t = now(); char* fresh = (char*)malloc(N); CK(hipMemcpy(fresh, d0, N, hipMemcpyDeviceToHost)); printf("pageable D2H into fresh malloc %.1f GB/s\n", N / (now() - t) / 1e9); free(fresh);
+    }
+    {   // can the library make a caller's FRESH output buffer cheaper to fill?  (the reference returns fresh Vecs)
+        FILE* f = fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r");
+        char line[128] = "?";
+        if (f) { if (!fgets(line, sizeof line, f)) line[0] = 0; fclose(f); }
+        printf("transparent_hugepage/enabled: %s", line);
+        for (int mode = 0; mode < 5; ++mode) {
+            char* fresh = (char*)aligned_alloc(1 << 21, N);
+            double t = now();
+            const char* what = "";
+            if (mode == 0) what = "plain (2 MiB-aligned allocation)";
+            if (mode == 1 || mode == 3 || mode == 4) { int rc = madvise(fresh, N, MADV_HUGEPAGE); what = rc ? "MADV_HUGEPAGE failed" : "MADV_HUGEPAGE"; }
+            if (mode == 2 || mode == 3 || mode == 4) {
+                const int T = mode == 4 ? 16 : 8;
+                std::vector<std::thread> th;
+                std::atomic<int> bad{0};
+                for (int i = 0; i < T; ++i)
+                    th.emplace_back([&, i] {
+                        const size_t per = ((N / T) >> 21) << 21;
+                        const size_t lo = i * per, hi = i == T - 1 ? N : lo + per;
+                        if (madvise(fresh + lo, hi - lo, 23 /* MADV_POPULATE_WRITE */)) bad++;
+                    });
+                for (auto& x : th) x.join();
+                what = mode == 2 ? (bad ? "MADV_POPULATE_WRITE x8 FAILED" : "MADV_POPULATE_WRITE x8 threads")
+                                 : mode == 3 ? (bad ? "HUGEPAGE + POPULATE_WRITE x8 FAILED" : "MADV_HUGEPAGE + MADV_POPULATE_WRITE x8 threads")
+                                             : (bad ? "HUGEPAGE + POPULATE_WRITE x16 FAILED" : "MADV_HUGEPAGE + MADV_POPULATE_WRITE x16 threads");
+            }
+            const double prep = now() - t;
+            CK(hipMemcpy(fresh, d0, N, hipMemcpyDeviceToHost));
+            const double all = now() - t;
+            printf("pageable D2H into fresh memory, %-48s: prepare %.1f ms, total %.1f ms = %.1f GB/s\n", what, prep * 1e3, all * 1e3, N / all / 1e9);
+            free(fresh);
+        }
     }
     for (int T : {1, 2, 4, 8, 16}) {
         double t = now(); par_copy((char*)pin0, pg, N, T); double a = now() - t;
