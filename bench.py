@@ -16,6 +16,7 @@ independent, there is no data-path collective).  Rank 0 prints ONE JSON line.
   extra      cfg3 encode/decode rates, element-wise rate, the register-resident modmul ceiling
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -53,6 +54,12 @@ def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prew
     for _ in range(warmup):
         step_fn()
     sync_fn()
+    # The interpreter's cyclic collector must not land in the timed region: with torch imported a full collection
+    # takes ~40 ms (seen as ONE 38 ms host call among thousands of 15 us ones, tools/time_needed_only.py), i.e. ten
+    # times the whole K = 20 region.  Collect now, switch it off for the K steps.
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier_fn()
     if events:
         events[2](events[0])
@@ -63,6 +70,8 @@ def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prew
         events[2](events[1])
     sync_fn()
     dt = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     barrier_fn()
     out = {"secs": max_reduce_fn(dt), "prewarm_ms": prewarm_ms, "prewarm_steps": pre_steps}
     if events:
