@@ -518,6 +518,12 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * two at it -- e.g. (1, 6144) before the eager run that precedes a graph capture makes mid-size decodes build their
  * table at once (nothing can be built during capture: a call whose table is missing then records the lane kernels). */
 ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);
+/* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have
+ * arrived (batch_recon.rs:371-389) -- has no OEC round: a chunk that fails the verification can only fail
+ * (DecodingError, robust_interpolate.rs:625).  Such a call is ONE kernel launch: the decode kernel writes the failure
+ * (status, zero coefficients, length 0) and its last workgroup the summary.  on = 0 sends those chunks through the
+ * OEC/Gao kernel as every other call does (A/B aid: same bytes either way; default on). */
+ShareErrorCode hbmpc_set_single_launch_decode(hbmpc_ctx* ctx, int on);
 /* test aid: workgroups of a matrix-core launch (0 = one per CU, the default); a small number makes a small batch walk
  * the multi-tile loop of every wave */
 ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups);

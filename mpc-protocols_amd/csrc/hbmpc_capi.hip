@@ -48,6 +48,7 @@ struct hbmpc_ctx {
     std::vector<void*> pin_free;                   // pinned, device-mapped staging blocks of small host-pointer calls (Stage)
     size_t wide_max_chunks = 8192;                 // batch_recover calls up to this many chunks (evaluations: a quarter of it) use the wave-per-chunk kernels
     bool second_chance = true;                     // flagged chunks try two cheap interpolation candidates before OEC/Gao
+    bool direct_fail = true;                       // a decode with no OEC round (S == d + t + 1) is ONE launch: failures are written by the first kernel
     bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
     bool matrix_cores = true;                      // large Fr decodes run the int8 MFMA formulation (kernels_mfma.hpp)
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
@@ -272,6 +273,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
         ctx->mfma_min_cached = std::min<size_t>(min_chunks, 6144);
         ctx->mfma_min_encode = std::min<size_t>(min_chunks, 4096);
     }
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_single_launch_decode(hbmpc_ctx* ctx, int on) {  // either field
+    if (!ctx) return InvalidInput;
+    ctx->direct_fail = on != 0;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups) {

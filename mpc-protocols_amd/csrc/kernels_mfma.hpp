@@ -204,6 +204,8 @@ struct MfmaRowsArgs {
     int role_nwg[MF_MAX_ROLES];
     uint8_t blk_role[64], blk_idx[64];
     MfmaRole role[MF_MAX_ROLES];
+    int direct;           // 1 (decode, ONE role): no OEC round exists, a chunk that fails the verification fails for good and this
+                          // kernel is the whole call (kernels_recover.hpp: fail_chunk / count_failures / finish_direct)
     int abl;              // microbenchmark ablations (tools/ubench_mfma.hip), 0 in the library: 1 = no epilogue arithmetic (loads and stores stay),
                           // 2 = no MFMAs, 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored
 };
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     constexpr int ROWB = M * 1024 + 128;
     constexpr int NT = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // role.nrows * ROWB
-    if (a.summary && blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
+    if (a.summary && !a.direct && blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
     const int blk8 = (int)blockIdx.x >> 3, role_id = a.blk_role[blk8];
     const int wg_in_role = (int)a.blk_idx[blk8] * 8 + ((int)blockIdx.x & 7);
     MfmaRole role = a.role[0];
@@ -329,6 +331,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                     uint32_t Rw[4];
                     if (a.abl & 1) Rw[0] = acc[cg][0], Rw[1] = acc[cg][5], Rw[2] = acc[cg][10], Rw[3] = acc[cg][15];  // no arithmetic, same stores
                     else reduce_tile(acc[cg], Rw, H);
+                    if (a.direct) {  // one role, the verify rows are behind us: a chunk that failed them gets zeros
+                        const unsigned long long mb = __ballot(bad[cg] != 0);
+                        if ((((uint32_t)mb | (uint32_t)(mb >> 32)) >> c) & 1u) Rw[0] = Rw[1] = Rw[2] = Rw[3] = 0u;
+                    }
                     uint8_t* qb = a.out_party_major ? a.out + k * a.out_stride * 32 : a.out + k * 32;  // wave-uniform
                     const uint32_t qo = g[cg] * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
                     if (live[cg] && (!(a.abl & 4) || Rw[0] == 0x12345u)) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
@@ -346,7 +352,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                     const bool ok = ((m32 >> c) & 1u) == 0;
                     const bool flag = live[cg] && !ok && h == 0;
                     const unsigned long long fm = __ballot(flag);
-                    if (fm != 0) {
+                    if (fm != 0 && a.direct) {  // count_failures: chunks ascend with the lane
+                        if (lane == __ffsll((long long)fm) - 1) {
+                            atomicAdd(a.counters, (uint32_t)__popcll(fm));
+                            atomicMax(a.counters + 1, 0xffffffffu - g[cg]);
+                            __threadfence();
+                        }
+                    } else if (fm != 0) {
                         const int leader = __ffsll((long long)fm) - 1;
                         uint32_t base = 0;
                         if (lane == leader) base = atomicAdd(a.counters, (uint32_t)__popcll(fm));
@@ -355,8 +367,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                         if (flag && slot < a.G) a.flagged[slot] = g[cg];  // the list has G entries (handoff_count)
                     }
                     if (live[cg] && h == 0) {
-                        if (a.status) a.status[g[cg]] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the fallback kernels
-                        if (a.ncoeffs && ok) a.ncoeffs[g[cg]] = M;
+                        if (a.status) a.status[g[cg]] = ok ? 0 : a.direct ? (uint8_t)DecodingError : 0xff;  // 0xff: pending, rewritten by the fallback kernels
+                        if (a.ncoeffs && (ok || a.direct)) a.ncoeffs[g[cg]] = ok ? M : 0;
                     }
                 }
             }
@@ -376,6 +388,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
         t += tstep;
     }
     (void)pf;
+    if (a.direct) finish_direct(a.counters, a.summary);
 }
 
 // Host side: cut `rows` table rows (the first nv of them verify rows) into roles of at most `cap` rows.  Everything in one

@@ -15,6 +15,7 @@
 // chunk-major coeffs[G][m] (or secrets[G]).
 #pragma once
 #include "fr_sat.hpp"
+#include "../../include/hbmpc_hip.h"
 #include "fr_u29.hpp"
 
 namespace hbmpc {
@@ -44,6 +45,7 @@ struct RecoverArgs {
     uint32_t* counters;      // [0] = number of flagged chunks (zero when the call starts: the previous call's last kernel
                              // leaves it so, k_unscale)
     uint32_t* summary;       // {n_fallback, n_failed, first_failed, first_error}: initialised by block 0 of this kernel
+    int direct;              // 1: the call has no OEC round and this kernel is all of it (see fail_chunk / finish_direct)
 };
 // Words that one kernel of a call hands to the next and that are WRITTEN WITH ATOMICS (the flagged-chunk counters,
 // the summary) must be read with an agent-scope atomic load (global_load ... sc1), never with a plain or scalar load:
@@ -65,7 +67,7 @@ HB_DEV size_t handoff_count(const uint32_t* counter, size_t G) {
 }
 // first kernel of a call: nothing else touches the summary before this kernel has finished
 HB_DEV void init_summary(const RecoverArgs& a) {
-    if (blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;
+    if (!a.direct && blockIdx.x == 0 && threadIdx.x < 4) a.summary[threadIdx.x] = threadIdx.x == 2 ? 0xffffffffu : 0u;  // direct: finish_direct writes it
 }
 
 template <class F>
@@ -79,6 +81,45 @@ HB_DEV void flag_chunks(bool bad, size_t g, const RecoverArgs& a) {
     base = __shfl(base, leader);
     const size_t slot = (size_t)base + __popcll(mask & ((1ull << lane) - 1ull));
     if (bad && slot < a.G) a.flagged[slot] = (uint32_t)g;  // the list has G entries (see handoff_count)
+}
+
+// A call with NO OEC round (S == d + t + 1 senders -- what BatchRecon passes, it decodes as soon as that many have
+// arrived, batch_recon.rs:371-389): a chunk that fails the verification can only fail (oec_decode's DecodingError,
+// robust_interpolate.rs:625), so the first kernel is the whole call ("direct").  A failing chunk writes its own failure
+// (what k_gao would have written: status, zero coefficients, length 0); failures are counted in counters[0] -- zero at
+// the start like every call's -- and the lowest failing chunk kept in counters[1] as 0xffffffff - g (zero = none); the
+// LAST block to finish (ticket counters[3]) turns the two into the summary and leaves the counters at zero.
+template <class F>
+HB_DEV void fail_chunk(size_t g, uint32_t* out, int out_width, uint32_t* ncoeffs, uint8_t* status) {
+    if (status) status[g] = (uint8_t)DecodingError;
+    if (ncoeffs) ncoeffs[g] = 0u;
+    for (int k = 0; k < out_width; ++k) F::store_lt2r(out + (g * (size_t)out_width + k) * F::EW, F::zero());
+}
+// g ascends with the lane: the lowest failing chunk of the wave is its first failing lane's
+HB_DEV void count_failures(bool bad, size_t g, uint32_t* counters) {
+    const unsigned long long mask = __ballot(bad);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    if (lane == __ffsll((long long)mask) - 1) {
+        atomicAdd(counters, (uint32_t)__popcll(mask));
+        atomicMax(counters + 1, 0xffffffffu - (uint32_t)g);
+        __threadfence();  // performed before this block takes its ticket
+    }
+}
+// every thread of every block, at the end of a direct kernel
+HB_DEV void finish_direct(uint32_t* counters, uint32_t* summary) {
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned nblocks = gridDim.x * gridDim.y;
+    if (atomicAdd(counters + 3, 1u) != nblocks - 1) return;
+    const uint32_t failed = load_handoff(counters), low = load_handoff(counters + 1);
+    if (summary) {
+        summary[0] = failed, summary[1] = failed;
+        summary[2] = failed ? 0xffffffffu - low : 0xffffffffu;
+        summary[3] = failed ? (uint32_t)DecodingError : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_handoff(counters + k, 0u);
 }
 
 // M = d + 1 known at compile time: the chunk's m interpolation inputs live in registers (9 M VGPRs).
@@ -148,14 +189,20 @@ __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
         const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * F::EW);
         ok = ok && F::eq_canon(p, ys);
     }
-    flag_chunks<F>(live && !ok, g, a);
-    if (!live) return;
-    if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
-    if (!ok) return;
     constexpr int OW = P0_ONLY ? 1 : M;
-    for (int k = 0; k < OW; ++k)
-        F::store_lt2r(a.out + (g * OW + k) * F::EW, dot_row<F, M>(y, bc + (size_t)k * M * F::NL));
-    if (a.ncoeffs) a.ncoeffs[g] = M;
+    if (a.direct) count_failures(live && !ok, g, a.counters);
+    else flag_chunks<F>(live && !ok, g, a);
+    if (live && !ok) {
+        if (a.direct) fail_chunk<F>(g, a.out, OW, a.ncoeffs, a.status);
+        else if (a.status) a.status[g] = 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
+    }
+    if (live && ok) {
+        if (a.status) a.status[g] = 0;
+        for (int k = 0; k < OW; ++k)
+            F::store_lt2r(a.out + (g * OW + k) * F::EW, dot_row<F, M>(y, bc + (size_t)k * M * F::NL));
+        if (a.ncoeffs) a.ncoeffs[g] = M;
+    }
+    if (a.direct) finish_direct(a.counters, a.summary);
 }
 
 // any m: inputs are re-read from global memory inside the dot products (they stay L2-resident).
@@ -186,12 +233,15 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
         const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + gg) * F::EW);
         ok = ok && F::eq_canon(p, ys);
     }
-    flag_chunks<F>(live && !ok, g, a);
-    if (!live) return;
-    if (a.status) a.status[g] = ok ? 0 : 0xff;
-    if (!ok) return;
     const int OW = P0_ONLY ? 1 : M;
-    for (int k = 0; k < OW; ++k) {
+    if (a.direct) count_failures(live && !ok, g, a.counters);
+    else flag_chunks<F>(live && !ok, g, a);
+    if (live && !ok) {
+        if (a.direct) fail_chunk<F>(g, a.out, OW, a.ncoeffs, a.status);
+        else if (a.status) a.status[g] = 0xff;
+    }
+    if (live && ok && a.status) a.status[g] = 0;
+    for (int k = 0; k < (live && ok ? OW : 0); ++k) {
         typename F::Acc acc;
         F::acc_zero(acc);
         const uint32_t* row = a.bc + (size_t)k * M * F::NL;
@@ -207,7 +257,8 @@ __global__ __launch_bounds__(256) void k_batch_recover_generic(RecoverArgs a) {
         F::acc_fold(acc);
         F::store_loose(a.out + (g * (size_t)OW + k) * F::EW, F::acc_reduce(acc));
     }
-    if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
+    if (live && ok && a.ncoeffs) a.ncoeffs[g] = (uint32_t)M;
+    if (a.direct) finish_direct(a.counters, a.summary);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -370,6 +421,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
         for (int w = 0; w < F::EW; ++w) ys[i * F::EW + w] = src[w];
     }
     __syncthreads();
+    auto chunk = [&]() __attribute__((always_inline)) {
     if (!live) return;
     auto dot = [&](int r) -> E {  // r < nv: verify row r; else output row r - nv
         const uint32_t* row = r < nv ? a.vm + (size_t)r * M * F::NL : a.bc + (size_t)(r - nv) * M * F::NL;
@@ -397,6 +449,18 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     }
     for (int r = lane + 64; r < nv; r += 64) bad = bad || !F::eq_canon(F::canon_loose(dot(r)), F::load(ys + (M + r) * F::EW));
     const bool ok = __ballot(bad) == 0;
+    if (!ok && a.direct) {  // no OEC round: the failure is final (fail_chunk, one lane per output element)
+        if (lane < ow) F::store_lt2r(a.out + (g * (size_t)ow + lane) * F::EW, F::zero());
+        for (int k = lane + 64; k < ow; k += 64) F::store_lt2r(a.out + (g * (size_t)ow + k) * F::EW, F::zero());
+        if (lane == 0) {
+            if (a.status) a.status[g] = (uint8_t)DecodingError;
+            if (a.ncoeffs) a.ncoeffs[g] = 0u;
+            atomicAdd(a.counters, 1u);
+            atomicMax(a.counters + 1, 0xffffffffu - (uint32_t)g);
+            __threadfence();
+        }
+        return;
+    }
     if (lane == 0) {
         if (a.status) a.status[g] = ok ? 0 : 0xff;  // 0xff: pending, rewritten by the OEC/Gao kernel
         if (!ok && !wa.fused) {
@@ -414,6 +478,9 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     if (have) F::store_loose(a.out + (g * (size_t)ow + (lane - nv)) * F::EW, kept);
     for (int r = lane + 64; r < nv + ow; r += 64)
         if (r >= nv) F::store_loose(a.out + (g * (size_t)ow + (r - nv)) * F::EW, dot(r));
+    };
+    chunk();
+    if (a.direct) finish_direct(a.counters, a.summary);
 }
 
 
