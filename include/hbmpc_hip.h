@@ -529,6 +529,12 @@ ShareErrorCode hbmpc_set_single_launch_decode(hbmpc_ctx* ctx, int on);
 ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups);
 /* test aid: 1 = route every shape through the generic (runtime-shaped) kernels */
 ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
+/* Secret hygiene.  The host-pointer calls stage their arguments through per-context pools (device buffers, pinned host
+ * blocks) that are recycled between calls, so copies of polynomial coefficients (secrets) and shares stay there until
+ * a later call overwrites them.  hbmpc_scrub_staging zeroes everything the pools hold (it drains the context's stream
+ * first); hbmpc_destroy does it before freeing.  Buffers the CALLER allocated (hbmpc_dev_alloc, its own host arrays) are
+ * the caller's to clear. */
+ShareErrorCode hbmpc_scrub_staging(hbmpc_ctx* ctx);
 /* The device-table cache of a context (twiddles, Vandermonde rows, one Lagrange/verify table and one OEC/Gao table
  * per sender set) is bounded: at 512 tables everything not referenced by a captured graph is evicted (unlinked now,
  * freed at the next eviction, so a concurrent call that already looked a table up never loses it).

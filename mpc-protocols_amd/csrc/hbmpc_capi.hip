@@ -244,10 +244,23 @@ extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_c
     *ctx_out = ctx;
     return ShareSuccess;
 }
+// Staging memory of the host-pointer API holds copies of what callers passed in (polynomial coefficients, i.e. secrets,
+// shares) until a later call overwrites it: zero what the pools hold.
+extern "C" ShareErrorCode hbmpc_scrub_staging(hbmpc_ctx* ctx) {
+    if (!ctx) return InvalidInput;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (auto& b : ctx->stage_free) HIP_TRY(ctx, hipMemsetAsync(b.first, 0, b.second, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (void* q : ctx->pin_free) memset(q, 0, (size_t)2048 << 10);  // Stage::BLOCK
+    return ShareSuccess;
+}
 extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hbmpc_scrub_staging(ctx);
     for (auto& kv : ctx->tables) (void)hipFree(kv.second.p);
     for (uint32_t* q : ctx->retired_tables) (void)hipFree(q);
     for (auto& kv : ctx->scratch) (void)hipFree(kv.second.p);

@@ -129,6 +129,9 @@ class Engine:
         """large Fr decodes on the matrix cores (int8 MFMA); min_chunks = 0 keeps the current threshold"""
         assert self.L.hbmpc_set_matrix_cores(self.ctx, C.c_int(1 if on else 0), C.c_size_t(min_chunks)) == 0
 
+    def scrub_staging(self):
+        assert self.L.hbmpc_scrub_staging(self.ctx) == 0
+
     def set_single_launch_decode(self, on: bool):
         assert self.L.hbmpc_set_single_launch_decode(self.ctx, C.c_int(1 if on else 0)) == 0
 

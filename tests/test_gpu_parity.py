@@ -510,3 +510,18 @@ def test_buffers_beyond_4_gib(eng):
     rc, want = O.compute_shares(xs, n, d)
     assert rc == 0 and np.array_equal(ys, want)
     torch.cuda.set_stream(torch.cuda.default_stream(dev))
+
+
+def test_scrub_staging_between_calls(eng):
+    """hbmpc_scrub_staging zeroes the pooled staging memory of the host-pointer calls (device buffers of a large call,
+    the pinned block of a small one); calls before and after it give the same bytes"""
+    for B in (3, 70000):
+        x = O.fill_random(31 + B, B * 6).reshape(B, 6, 4)
+        rc, want = O.compute_shares(x, 16, 5)
+        rc1, y1 = eng.compute_shares(x, 16, 5)
+        eng.scrub_staging()
+        rc2, y2 = eng.compute_shares(x, 16, 5)
+        eng.scrub_staging()
+        assert rc == rc1 == rc2 == 0 and np.array_equal(y1, want) and np.array_equal(y2, want)
+        got = eng.batch_recover(list(range(16)), y2, 16, 5, 5)
+        assert got[0] == 0 and np.array_equal(got[1], x)
