@@ -43,6 +43,13 @@ def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prew
     EXACTLY K steps bracketed by barrier+sync.  `events` = (ev0, ev1, record) brackets the SAME K launches with two HIP
     events on the launch stream: kernel_ms comes from the timed region itself.  Returns a dict; "secs" is the
     max-over-ranks wall time of the K steps."""
+    # The interpreter's cyclic collector must not land in the timed region: with torch imported a full collection takes
+    # ~40 ms (seen as ONE 38 ms host call among thousands of 15 us ones, tools/time_needed_only.py), ten times the whole
+    # K = 20 region.  Collect NOW -- before the pre-warm, so that the pause does not let the chip's clocks fall again
+    # right before the timed launches -- and keep it off until they are done.
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     t_pre = time.perf_counter()
     pre_steps = 0
     while prewarm_s > 0 and time.perf_counter() - t_pre < prewarm_s:
@@ -54,12 +61,6 @@ def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prew
     for _ in range(warmup):
         step_fn()
     sync_fn()
-    # The interpreter's cyclic collector must not land in the timed region: with torch imported a full collection
-    # takes ~40 ms (seen as ONE 38 ms host call among thousands of 15 us ones, tools/time_needed_only.py), i.e. ten
-    # times the whole K = 20 region.  Collect now, switch it off for the K steps.
-    gc.collect()
-    gc_was_on = gc.isenabled()
-    gc.disable()
     barrier_fn()
     if events:
         events[2](events[0])
