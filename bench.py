@@ -411,7 +411,8 @@ def bench_pipeline(ctx):
         fp = setup_fpmul(eng, torch, dev, stream, n, t, N, k, f)
         fp.run(check=True)
         step, unit, pipe, result_ptr = fp.run, "fpmuls/s", fp, fp.out
-        what = f"fpmul n={n} t={t} (k, f) = ({k}, {f}), 2^18 fixed-point multiplications, {N} on this rank"
+        what = (f"fpmul n={n} t={t} (k, f) = ({k}, {f}), 2^18 fixed-point multiplications, {N} on this rank; every open "
+                f"interpolates from the first 2t+1 = {2 * t + 1} senders, as the reference does (multiplication.rs:388, truncpr.rs:202)")
     torch.cuda.synchronize()
     tm = timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize, ctx["barrier"], ctx["max_reduce"],
                      prewarm_s=args.prewarm_seconds, events=ctx["events"]())

@@ -140,9 +140,11 @@ class TripleGen : public CapturablePipeline {
 
 // Fixed-point multiplication of N element pairs for n parties: Beaver mul (a-x, b-y opened by direct robust
 // interpolation, the RBC path FPMulNode always takes) followed by TruncPr with k-bit values and m fractional bits.
+// open_senders: how many parties' shares an open interpolates from (0 = the default 2t+1: the reference opens as soon as
+// that many have arrived, multiplication.rs:388,617, truncpr.rs:202 -- with d = t a decode with no OEC round, one launch).
 class FpMul : public CapturablePipeline {
   public:
-    FpMul(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, size_t k, size_t m, void* stream)
+    FpMul(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, size_t k, size_t m, void* stream, size_t open_senders = 0)
         : CapturablePipeline(ctx, stream), n_(n), t_(t), N_(N), k_(k), m_(m),
           arena_(ctx, ((12 + m) * n * N + 4 * N) * 32 + 4 * N + (1 << 14)) {
         U256** per_party[] = {&x, &y, &ta, &tb, &tc, &rint, &dsh_, &esh_, &z, &rdash_, &osh_, &out};
@@ -151,7 +153,9 @@ class FpMul : public CapturablePipeline {
         dop_ = arena_.take(N), eop_ = arena_.take(N), cop_ = arena_.take(N);
         status_ = static_cast<uint8_t*>(arena_.take_bytes(N));
         summ = static_cast<hbmpc_recover_summary*>(arena_.take_bytes(64));
-        for (size_t i = 0; i < n; ++i) ids_.push_back(i);
+        if (open_senders == 0) open_senders = 2 * t + 1;
+        if (open_senders < 2 * t + 1 || open_senders > n) throw std::invalid_argument("FpMul: 2t+1 <= open_senders <= n");
+        for (size_t i = 0; i < open_senders; ++i) ids_.push_back(i);
     }
     void run() override {
         const size_t n = n_, N = N_;
@@ -170,7 +174,7 @@ class FpMul : public CapturablePipeline {
 
   private:
     void open(const U256* shares, U256* dst, const char* what) {
-        pl_check(hbmpc_dev_batch_recover_p0(ctx_, ids_.data(), n_, shares, N_, n_, t_, t_, dst, status_, summ, stream_), ctx_, what);
+        pl_check(hbmpc_dev_batch_recover_p0(ctx_, ids_.data(), ids_.size(), shares, N_, n_, t_, t_, dst, status_, summ, stream_), ctx_, what);
     }
     size_t n_, t_, N_, k_, m_;
     DeviceArena arena_;

@@ -133,10 +133,16 @@ class TripleGen(_Capturable):
 class FpMul(_Capturable):
     """Fixed-point multiplication of N element pairs for n parties: Beaver mul (a-x, b-y opened by direct
     robust interpolation, i.e. the RBC path of Multiply::init for < t+1 leftovers that FPMulNode always
-    takes) followed by TruncPr with k-bit values and m fractional bits."""
+    takes) followed by TruncPr with k-bit values and m fractional bits.
+    open_senders: how many parties' shares an open interpolates from.  Default 2t+1: the reference opens as soon as that
+    many have arrived (multiplication.rs:388,617 `received_shares.len() >= 2 * self.t + 1`, truncpr.rs:202
+    `open_buf.len() < 2 * self.t + 1`), i.e. from the first 2t+1 senders -- with d = t that is exactly d + t + 1, a decode
+    with no OEC round, which the library runs as one launch.  n = every party's share (OEC rounds available)."""
 
-    def __init__(self, eng, n, t, N, k, m, stream=0):
+    def __init__(self, eng, n, t, N, k, m, stream=0, open_senders=None):
         self.eng, self.n, self.t, self.N, self.k, self.m, self.stream = eng, n, t, N, k, m, stream
+        self.open_senders = 2 * t + 1 if open_senders is None else open_senders
+        assert 2 * t + 1 <= self.open_senders <= n
         self.arena = DeviceArena(eng, ((12 + m) * n * N + 4 * N) * U + 4 * N + (1 << 14))
         ar = self.arena
         (self.x, self.y, self.ta, self.tb, self.tc, self.rint, self.dsh, self.esh, self.z, self.rdash, self.osh,
@@ -153,7 +159,7 @@ class FpMul(_Capturable):
 
     def _open(self, shares, out, what):
         e, n, t, N, s = self.eng, self.n, self.t, self.N, self.stream
-        _check(e.dev_batch_recover(list(range(n)), shares, N, n, t, t, out, 0, self.status, self.summ, s, p0=True), e, what)
+        _check(e.dev_batch_recover(list(range(self.open_senders)), shares, N, n, t, t, out, 0, self.status, self.summ, s, p0=True), e, what)
         if self.check:
             _summary_ok(e, self.summ, what, s)
 

@@ -57,8 +57,9 @@ def test_triple_gen_pipeline(pkg_eng, n, t, groups):
         assert GU.eq(c[p], O.triple_finalize(srt[p], opened)[1])
 
 
+@pytest.mark.parametrize("senders", ["2t+1", "n"])   # the reference opens from the first 2t+1 arrivals; n: OEC rounds available
 @pytest.mark.parametrize("n,t,N,k,m", [(4, 1, 50, 16, 4), (7, 2, 64, 16, 4), (16, 5, 200, 32, 16)])
-def test_fpmul_pipeline(pkg_eng, n, t, N, k, m):
+def test_fpmul_pipeline(pkg_eng, n, t, N, k, m, senders):
     pkg, eng = pkg_eng
     rng = np.random.default_rng(n)
     half = (k - 2) // 2
@@ -73,7 +74,7 @@ def test_fpmul_pipeline(pkg_eng, n, t, N, k, m):
     sta, stb, stc = share_all(ta, n, t, 33), share_all(tb, n, t, 34), share_all(tc, n, t, 35)
     srint = share_all(O.ints_to_u256(rints), n, t, 36)
     sbits = np.stack([share_all(O.ints_to_u256([int(v) for v in bits[j]]), n, t, 40 + j) for j in range(m)], axis=1)  # [n][m][N]
-    fp = pkg.pipelines.FpMul(eng, n, t, N, k, m)
+    fp = pkg.pipelines.FpMul(eng, n, t, N, k, m, open_senders=None if senders == "2t+1" else n)
     fp.upload(sx, sy, sta, stb, stc, np.ascontiguousarray(sbits), srint)
     fp.run()
     z = fp.download("z")
