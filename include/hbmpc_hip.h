@@ -510,6 +510,9 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * vector (a function of n, d, t and the sender ids) times batch data, i.e. an int8 GEMM over the bytes of the canonical
  * elements followed by one carry pass and one small-quotient reduction (csrc/kernels_mfma.hpp).  Results are
  * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both).
+ * A Goldilocks context has the same switch: its decodes and its encodes on domains beyond 16 points run on the matrix
+ * cores from 4 096 chunks for 2 <= d + 1 <= 16 (csrc/kernels_mfma_gl.hpp: the table is a few KB, fits the LDS whole and
+ * costs microseconds to build, so there is no sender-set rule).
  * min_chunks = 0 keeps the current thresholds.  Defaults: a decode of >= 65 536 chunks always takes the path (a sender
  * set not seen before costs ~0.7 ms of host table construction, more than a smaller call saves); a decode of
  * 6 144 .. 65 535 chunks takes it when the sender set's table is already cached, and builds it the SECOND time the

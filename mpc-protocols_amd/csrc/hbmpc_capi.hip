@@ -19,7 +19,9 @@
 #include "launchers.hpp"
 #include "tables.hpp"
 #include "tables_mfma.hpp"
+#include "tables_mfma_gl.hpp"
 #include "kernels_mfma.hpp"
+#include "kernels_mfma_gl.hpp"
 
 using namespace hbmpc;
 
@@ -54,6 +56,7 @@ struct hbmpc_ctx {
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
     size_t mfma_min_cached = 6144;                 // ... and from this many when the sender set's table is cached or the set recurs
     size_t mfma_min_encode = 4096;                 // encodes (one table per (n, d), never rebuilt): from this many chunks
+    size_t mfma_min_gold = 4096;                   // Goldilocks (tiny tables, one workgroup kind): from this many chunks
     std::map<std::string, int> mfma_seen;          // sender sets of mid-size decodes that went to the lane kernels, by sightings
     int n_cus = 256;
     int mfma_wgs = 0;                              // test aid: workgroups of a matrix-core launch (0 = one per CU)
@@ -277,11 +280,11 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     ctx->impl = impl;
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks) {
+extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks) {  // either field
     if (!ctx) return InvalidInput;
-    REQ_FR(ctx);
     ctx->matrix_cores = on != 0;
     if (min_chunks) {
+        ctx->mfma_min_gold = std::min<size_t>(min_chunks, 4096);
         ctx->mfma_min_chunks = min_chunks;
         ctx->mfma_min_cached = std::min<size_t>(min_chunks, 6144);
         ctx->mfma_min_encode = std::min<size_t>(min_chunks, 4096);
@@ -502,6 +505,40 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
            launch_mfma_rows_c(mi, a, ctx->device, s) || launch_mfma_rows_d(mi, a, ctx->device, s);
 }
 
+// the same over Goldilocks (kernels_mfma_gl.hpp): all n rows in every workgroup's LDS
+static bool try_mfma_eval_gl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t dp1, EvalOut y, hipStream_t s,
+                             ShareErrorCode* rc_out) {
+    *rc_out = ShareSuccess;
+    if (mfgl_table_bytes(n, dp1) + 2048 > 160 * 1024) return false;
+    const uint32_t* tab;
+    *rc_out = get_table(ctx, key("mfvandgl", {n, dp1}, ctx->impl), [&] {
+        std::vector<HGl> el = domain_elements<HGl>(n, n);
+        std::vector<std::vector<HGl>> V(n, std::vector<HGl>(dp1));
+        for (size_t j = 0; j < n; ++j) {
+            HGl p = HGl::one();
+            for (size_t k = 0; k < dp1; ++k) {
+                V[j][k] = p;
+                p = p * el[j];
+            }
+        }
+        return build_mfma_table_gl(V, dp1);
+    }, &tab);
+    if (*rc_out != ShareSuccess) return true;
+    mf::MfmaGlArgs a;
+    memset(&a, 0, sizeof a);
+    a.in = (const uint8_t*)x;
+    a.G = G;
+    a.in_chunk_major = 1;
+    a.table = (const uint8_t*)tab;
+    a.m = (int)dp1, a.nrows = (int)n, a.nv = 0;
+    a.out = (uint8_t*)y.y;
+    a.out_party_major = 1;
+    a.out_stride = y.ys ? y.ys : G;
+    const size_t ntiles = (G + 31) / 32;
+    const unsigned grid = (unsigned)std::min<size_t>((ntiles + 3) / 4, (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus * 4));
+    return launch_mfma_rows_gl(a, grid, ctx->device, s);
+}
+
 static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, EvalOut y,
                                 hipStream_t s) {
     const size_t size = domain_size(n), dp1 = d + 1;
@@ -534,6 +571,9 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
                try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf)) {
         // domains beyond 16 points: the dense n x (d + 1) map on the matrix cores beats the multi-pass FFT (config 3's
         // encode: 0.45 ms against 0.62 ms); up to 16 points the single-pass FFT stays (config 2: a tie at 0.187 ms)
+        return rc_mf;
+    } else if (gold && ctx->matrix_cores && !ctx->force_generic && y.parties == 1 && dp1 >= 2 && dp1 <= MFGL_MAX_M &&
+               G >= ctx->mfma_min_gold && n <= 255 && try_mfma_eval_gl(ctx, x, G, n, dp1, y, s, &rc_mf)) {
         return rc_mf;
     } else if ((impl == IMPL_U29 || gold) && size <= 256 && dp1 <= 32 && !ctx->force_generic) {
         const size_t P = size / 16;

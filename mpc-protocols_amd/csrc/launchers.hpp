@@ -47,7 +47,8 @@ bool launch_recover_c(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipS
 bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 // matrix-core form of the constant-matrix maps (kernels_mfma.hpp), m = 2 .. 15; false when m is not instantiated there
-namespace mf { struct MfmaRowsArgs; }
+namespace mf { struct MfmaRowsArgs; struct MfmaGlArgs; }
+bool launch_mfma_rows_gl(const mf::MfmaGlArgs& a, unsigned grid, int device, hipStream_t s);  // Goldilocks (kernels_mfma_gl.hpp)
 bool launch_mfma_rows_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 bool launch_mfma_rows_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 bool launch_mfma_rows_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);

@@ -23,17 +23,21 @@ def _eng():
     e.close()
 
 
-@pytest.fixture(params=["fast", "lane", "generic"])
+@pytest.fixture(params=["fast", "lane", "generic", "mfma", "mfma-gao"])
 def eng(request, _eng):
     """fast: the pruned-FFT / register-resident kernels instantiated for Goldilocks; generic: the runtime-shaped
-    Horner / re-reading kernels (what shapes outside the templates fall back to)"""
+    Horner / re-reading kernels (what shapes outside the templates fall back to); mfma: the matrix-core kernel
+    (kernels_mfma_gl.hpp) at every size it covers (2 <= d + 1 <= 16), with and without the second-chance candidates"""
+    mf = request.param.startswith("mfma")
     _eng.set_force_generic(request.param == "generic")
-    _eng.set_small_batch_chunks(0 if request.param == "lane" else 8192)  # lane: the large-batch kernels at every size
-    _eng.set_second_chance(request.param == "fast")  # the other modes: every flagged chunk goes to the OEC/Gao kernel
+    _eng.set_small_batch_chunks(0 if request.param == "lane" or mf else 8192)  # lane: the large-batch kernels at every size
+    _eng.set_second_chance(request.param in ("fast", "mfma"))  # the other modes: every flagged chunk goes to the OEC/Gao kernel
+    _eng.set_matrix_cores(mf, 1 if mf else 0)
     yield _eng
     _eng.set_force_generic(False)
     _eng.set_small_batch_chunks(8192)
     _eng.set_second_chance(True)
+    _eng.set_matrix_cores(True, 65536)
 
 
 def rnd(seed, *shape):

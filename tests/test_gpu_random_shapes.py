@@ -94,11 +94,14 @@ def test_random_encode_decode(engines, field, seed):
     eng.set_small_batch_chunks(0)                             # the lane-per-chunk kernels of the large batches and
     eng.set_second_chance(False)                              # OEC/Gao for every flagged chunk ...
     lane = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
-    if field == "fr":                                         # the matrix-core decode of the large batches (2 <= d + 1 <= 15,
-        eng.set_matrix_cores(True, 1)                         # other shapes fall through to the lane kernels): same bytes
-        mf = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
-        eng.set_matrix_cores(True, 65536)
-        assert lane[0] == mf[0] and all(np.array_equal(u, v) for u, v in zip(lane[1:], mf[1:]))
+    # the matrix-core decode of the large batches (Fr: 2 <= d + 1 <= 15, Goldilocks: <= 16; other shapes fall through to the
+    # lane kernels) and the matrix-core encode: same bytes
+    eng.set_matrix_cores(True, 1)
+    mf = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)
+    rcm, ym = eng.vandermonde_apply(to_arr(field, polys), n, d)
+    eng.set_matrix_cores(True, 65536)
+    assert lane[0] == mf[0] and all(np.array_equal(u, v) for u, v in zip(lane[1:], mf[1:]))
+    assert rcm == 0 and np.array_equal(ym, y0)
     eng.set_small_batch_chunks(8192)                          # ... and the defaults (wave-per-chunk kernel, second-
     eng.set_second_chance(True)                               # chance candidates before OEC/Gao): same bytes
     rc, co, nco, st = eng.batch_recover(ids, to_arr(field, [ev[i] for i in ids]), n, d, t)

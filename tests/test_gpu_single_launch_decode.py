@@ -122,3 +122,69 @@ def test_every_chunk_fails():
             assert list(su) == [G, G, 0, DECODING_ERROR]
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("family,n,d,t,G", [("wide", 16, 5, 5, 300), ("lane", 16, 5, 5, 9001), ("mfma", 16, 5, 5, 9001),
+                                            ("mfma", 31, 10, 10, 5003), ("mfma", 16, 10, 5, 40001), ("mfma", 7, 2, 2, 64)])
+@pytest.mark.parametrize("p0", [False, True])
+def test_goldilocks_one_launch(family, n, d, t, G, p0):
+    """the same over the small field (hbmpc_gl_*): good chunks return the polynomial that was shared, failing chunks fail
+    the way the oracle's oec_decode does with no round to run, and both launch sequences agree byte for byte"""
+    import random
+    from oracle.spec_gl import P, S
+    e = load_package().Engine(0, field="goldilocks")
+    try:
+        if family == "mfma":
+            e.set_small_batch_chunks(0)
+            e.set_matrix_cores(True, 1)
+        else:
+            e.set_matrix_cores(False)
+        rng = random.Random(n * 100 + d)
+        x = np.array([rng.randrange(P) for _ in range(G * (d + 1))], dtype=np.uint64).reshape(G, d + 1)
+        rc, y = e.vandermonde_apply(x, n, d)
+        assert rc == 0
+        needed = d + t + 1
+        ids = list(range(n))[-needed:]
+        ev = np.ascontiguousarray(y[ids])
+        bad = sorted({g for g in (0, 1, 31, 32, G // 2, G - 1) if g < G}) if t else []
+        for k, g in enumerate(bad):
+            ev[(d + 1 + k) % needed, g] ^= np.uint64(1 + k)
+        # the oracle on the chunks that were touched: DecodingError with exactly d + t + 1 shares and one of them wrong
+        for g in bad[:3]:
+            with pytest.raises(S.ShareErr) as err:
+                S.recover_secret([S.Share(int(ev[i][g]), ids[i], d) for i in range(needed)], n, t)
+            assert err.value.code == DECODING_ERROR
+        ow = 1 if p0 else d + 1
+        want = (x[:, :1] if p0 else x).copy()
+        want[bad] = 0
+        res = {}
+        for on in (True, False):
+            e.set_single_launch_decode(on)
+            for rep in range(2):
+                dev_ev, dev_out, dev_st, dev_nc, dev_su = (e.dev_alloc(ev.nbytes), e.dev_alloc(G * ow * 8), e.dev_alloc(G), e.dev_alloc(G * 4),
+                                                           e.dev_alloc(64))
+                try:
+                    e.h2d(dev_ev, ev)
+                    e.h2d(dev_out, np.full(G * ow, 0xEEEEEEEEEEEEEEEE, dtype=np.uint64))
+                    rc = e.dev_batch_recover(ids, dev_ev, G, n, d, t, dev_out, 0 if p0 else dev_nc, dev_st, dev_su, 0, p0=p0)
+                    assert rc == 0, e.last_error()
+                    out, st, nc, su = np.zeros((G, ow), dtype=np.uint64), np.zeros(G, dtype=np.uint8), np.zeros(G, dtype=np.uint32), np.zeros(4, dtype=np.uint32)
+                    e.d2h(out, dev_out)
+                    e.d2h(st, dev_st)
+                    if not p0:
+                        e.d2h(nc, dev_nc)
+                    e.d2h(su, dev_su)
+                    e.sync()
+                finally:
+                    for p in (dev_ev, dev_out, dev_st, dev_nc, dev_su):
+                        e.dev_free(p)
+                assert np.array_equal(out, want), (on, rep)
+                assert [int(v) for v in np.nonzero(st)[0]] == bad and all(st[g] == DECODING_ERROR for g in bad), (on, rep)
+                if not p0:
+                    assert all(nc[g] == 0 for g in bad) and int((nc != d + 1).sum()) == len(bad)
+                nb = len(bad)
+                assert list(su) == [nb, nb, bad[0] if nb else 0xFFFFFFFF, DECODING_ERROR if nb else 0], (on, rep, list(su))
+            res[on] = (out, st, nc)
+        assert all(np.array_equal(u, v) for u, v in zip(res[True], res[False]))
+    finally:
+        e.close()
