@@ -305,8 +305,11 @@ HB_DEV typename F::E second_dot(const SecondArgs& a, size_t g, int ws, const uin
     F::acc_fold(acc);
     return F::canon_loose(F::acc_reduce(acc));
 }
+// true: resolved (coefficients, length and status written); false: the chunk goes on to OEC/Gao.  No atomics in here: the
+// caller tallies a wave's results with ONE atomic each (a batch in which every chunk is flagged made 2^20 atomic
+// increments of one word)
 template <class F>
-HB_DEV void second_chance_one(const SecondArgs& a, size_t g, int& first) {
+HB_DEV bool second_chance_one(const SecondArgs& a, size_t g, int& first) {
     using E = typename F::E;
     const int M = a.m;
     // liars are usually the same senders in every chunk of a batch: start with the window that resolved this lane's
@@ -332,12 +335,10 @@ HB_DEV void second_chance_one(const SecondArgs& a, size_t g, int& first) {
         }
         if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)len;
         if (a.status) a.status[g] = 1;
-        atomicAdd(&a.summary[0], 1u);
         first = w;
-        return;
+        return true;
     }
-    const uint32_t slot = atomicAdd(&a.counters[1], 1u);
-    if (slot < a.G) a.flagged2[slot] = (uint32_t)g;
+    return false;
 }
 // The same decision with a whole wave per flagged chunk (lane = table row): used when the flagged list is short
 // enough to give every chunk a wave -- one lying share in a one-polynomial recover_secret then costs two dot
@@ -393,8 +394,110 @@ __global__ __launch_bounds__(256) void k_second_chance(SecondArgs a) {
         return;
     }
     const size_t step = (size_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
     int first = 0;
-    for (size_t fi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; fi < count; fi += step) second_chance_one<F>(a, a.flagged[fi], first);
+    uint32_t resolved = 0;
+    // wave-uniform trip count (the ballots below need every lane of the wave in the loop)
+    for (size_t base = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < count; base += step) {
+        const size_t fi = base + lane;
+        const bool valid = fi < count;
+        const uint32_t g = valid ? a.flagged[fi] : 0u;
+        const bool done = valid && second_chance_one<F>(a, g, first);
+        resolved += done ? 1u : 0u;
+        const unsigned long long left = __ballot(valid && !done);  // on to OEC/Gao: one slot allocation per wave
+        if (left != 0) {
+            const int leader = __ffsll((long long)left) - 1;
+            uint32_t slot0 = 0;
+            if (lane == leader) slot0 = atomicAdd(&a.counters[1], (uint32_t)__popcll(left));
+            slot0 = __shfl(slot0, leader);
+            const size_t slot = (size_t)slot0 + __popcll(left & ((1ull << lane) - 1ull));
+            if (valid && !done && slot < a.G) a.flagged2[slot] = g;
+        }
+    }
+    // one tally per wave
+    for (int off = 32; off > 0; off >>= 1) resolved += __shfl_down(resolved, off);
+    if (lane == 0 && resolved) atomicAdd(&a.summary[0], resolved);
+}
+
+// Long lists (a Byzantine sender flags EVERY chunk of a batch), U29, m known at compile time: the lane-per-chunk walk with
+// the machinery of k_batch_recover -- the window's m inputs in registers, its table staged in LDS once per block and
+// window, constants fed to the multiply-accumulates as scalars.  For that the candidates are tried in the SAME order by
+// every lane of a block (the generic form lets each lane start with the window that resolved its previous chunk and
+// re-reads inputs and constants per term: 2.65 ms for 2^20 chunks of config 3 against 0.875 ms for the optimistic kernel
+// that does two thirds of the products).  The order of the candidates cannot change the result -- an accepted one is THE
+// polynomial -- so a block starts with the window that last accepted something.  ev[w] and bc[w] are contiguous
+// (tables.hpp, SecondTables::layout): (P - m) check rows, then m coefficient rows.
+template <class F, int M>
+__global__ __launch_bounds__(256, 2) void k_second_chance_m(SecondArgs a) {
+    using E = typename F::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t tab[];
+    const size_t count = handoff_count(a.counters, a.G);
+    const int lane = threadIdx.x & 63;
+    const size_t nwaves = (size_t)gridDim.x * (blockDim.x >> 6);
+    // this lane form overtakes the wave form early: 10 485 flagged chunks of config 3 take 0.15 ms as waves, 0.11 ms as lanes
+    if (count <= nwaves && a.P - M <= 64) {  // short list: a wave per chunk (k_second_chance)
+        for (size_t fi = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); fi < count; fi += nwaves)
+            second_chance_wave<F>(a, a.flagged[fi]);
+        return;
+    }
+    const int checks = a.P - M, tab_words = a.P * M * F::NL;
+    int first = 0;
+    uint32_t resolved = 0;
+    for (size_t base = (size_t)blockIdx.x * 256; base < count; base += (size_t)gridDim.x * 256) {  // block-uniform
+        const size_t fi = base + threadIdx.x;
+        const bool valid = fi < count;
+        const uint32_t g = a.flagged[valid ? fi : count - 1];
+        bool pending = valid;
+        int next_first = first;
+        bool have_next = false;
+        for (int i = 0; i < a.n_windows; ++i) {
+            if (!__syncthreads_or(pending)) break;  // also: everybody is done with the previous window's table
+            const int w = first + i < a.n_windows ? first + i : first + i - a.n_windows;
+            const int ws = a.win_start[w];
+            for (int k = threadIdx.x; k < tab_words; k += 256) tab[k] = a.ev[w][k];
+            __syncthreads();
+            E y[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) y[j] = F::load(a.evals + ((size_t)a.rows[ws + j] * a.row_stride + g) * F::EW);
+            int mism = 0;
+            for (int e = 0; e < checks; ++e) {
+                const int s = e < ws ? e : e + M;  // e-th position outside [ws, ws + M)
+                const E p = F::cond_sub_r(dot_row<F, M>(y, tab + (size_t)e * M * F::NL));
+                const E ys = F::load(a.evals + ((size_t)a.rows[s] * a.row_stride + g) * F::EW);
+                mism += F::eq_canon(p, ys) ? 0 : 1;
+                if (__ballot(pending && mism <= a.rmax) == 0) break;  // nobody in this wave can still accept this window
+            }
+            const bool acc = pending && mism <= a.rmax;
+            if (__ballot(acc) != 0) {  // coefficients, zero padded by construction; DensePolynomial length for the trimmed row
+                int len = 0;
+                const int kmax = a.ncoeffs ? M : (a.out_width < M ? a.out_width : M);
+                for (int k = 0; k < kmax; ++k) {
+                    const E c = F::cond_sub_r(dot_row<F, M>(y, tab + (size_t)(checks + k) * M * F::NL));
+                    if (!F::is_zero_canon(c)) len = k + 1;
+                    if (acc && k < a.out_width) F::store_lt2r(a.out + (g * (size_t)a.out_width + k) * F::EW, c);
+                }
+                if (acc) {
+                    if (a.ncoeffs) a.ncoeffs[g] = (uint32_t)len;
+                    if (a.status) a.status[g] = 1;
+                    ++resolved;
+                    pending = false;
+                }
+            }
+            if (!have_next && __syncthreads_or(acc)) next_first = w, have_next = true;
+        }
+        first = next_first;
+        const unsigned long long left = __ballot(pending);  // on to OEC/Gao: one slot allocation per wave
+        if (left != 0) {
+            const int leader = __ffsll((long long)left) - 1;
+            uint32_t slot0 = 0;
+            if (lane == leader) slot0 = atomicAdd(&a.counters[1], (uint32_t)__popcll(left));
+            slot0 = __shfl(slot0, leader);
+            const size_t slot = (size_t)slot0 + __popcll(left & ((1ull << lane) - 1ull));
+            if (pending && slot < a.G) a.flagged2[slot] = g;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) resolved += __shfl_down(resolved, off);
+    if (lane == 0 && resolved) atomicAdd(&a.summary[0], resolved);
 }
 
 // Small batches (the regime the protocols really run in: one reconstruction, a few hundred elements per message):

@@ -58,6 +58,7 @@ void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, con
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);
+bool launch_second_chance_m(int m, const SecondArgs& a, unsigned grid, hipStream_t s);  // U29, m = 2 .. 16 at compile time; false otherwise
 // OEC / Gao, matvec
 void launch_gao_u29(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s, bool inline_unscale);
 void launch_gao_sat(const GaoArgs& ga, size_t n, unsigned grid, hipStream_t s, bool inline_unscale);
