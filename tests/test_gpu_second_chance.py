@@ -71,9 +71,14 @@ def test_every_liar_pattern(env, n, t, d, present, max_liars, sample):
     eng.set_second_chance(True)
     eng.set_small_batch_chunks(0)
     sep = eng.batch_recover(ids, arr, n, d, t)
+    # ... and with the runtime-shaped kernels (Fr: k_second_chance instead of k_second_chance_m<M> for the long list)
+    eng.set_force_generic(True)
+    gen = eng.batch_recover(ids, arr, n, d, t)
+    eng.set_force_generic(False)
     eng.set_small_batch_chunks(8192)
     (rc1, co1, nco1, st1), (rc0, co0, nco0, st0) = results
     assert sep[0] == rc1 and all(np.array_equal(u, v) for u, v in zip(sep[1:], (co1, nco1, st1)))
+    assert gen[0] == rc1 and all(np.array_equal(u, v) for u, v in zip(gen[1:], (co1, nco1, st1)))
     assert rc1 == rc0 and np.array_equal(st1, st0) and np.array_equal(nco1, nco0)
     good = st1 <= 1
     assert np.array_equal(co1[good], co0[good])
