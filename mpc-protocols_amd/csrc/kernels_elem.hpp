@@ -14,13 +14,16 @@ struct ElemConsts {
     uint32_t c1[9];     // kernel-specific constant 1 (e.g. 2^(k-1) as a canonical element in limb form)
 };
 
+// Party-batched launches have gridDim.y = parties; per-party arrays are [party][N] (index ip), public operands -- the
+// opened values every party shares -- are [N] (index i).  Blocks are dispatched x-fastest, so the linear block id is
+// re-read as (element block, party) with the PARTY fastest: the parties of one element range run back to back and the
+// public operand is fetched from HBM once, not once per party (config 4's triple_finalize: 16 x 134 MB of re-reads that
+// neither the L2 nor the 256 MB memory-side cache held across a 400 MB party pass).  gridDim.y = 1: i as always.
 #define HB_GID                                                                 \
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;            \
+    const size_t lin_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x;           \
+    const size_t i = (lin_ / gridDim.y) * blockDim.x + threadIdx.x;            \
     if (i >= N) return;
-
-// party-batched launches: blockIdx.y = party; per-party arrays are [party][N] (index ip), public operands -- the
-// opened values every party shares -- are [N] (index i)
-#define HB_PID const size_t ip = (size_t)blockIdx.y * N + i;
+#define HB_PID const size_t ip = (lin_ % gridDim.y) * N + i;
 
 enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2 };
 
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void k_truncpr_rdash(const uint32_t* __restric
             F::acc_fold(acc);
             pending = 1;
         }
-        F::acc_mac(acc, F::load(r_bits + (((size_t)blockIdx.y * m + j) * N + i) * F::EW), pow2 + (size_t)j * F::NL);
+        F::acc_mac(acc, F::load(r_bits + (((lin_ % gridDim.y) * m + j) * N + i) * F::EW), pow2 + (size_t)j * F::NL);
         ++pending;
     }
     F::acc_fold(acc);
