@@ -1084,7 +1084,7 @@ static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const v
     ELEM_PROLOGUE
     CHECK_PARTIES(parties);
     const ElemConsts cs = elem_consts(ctx->impl);
-    BY_FIELD_P(parties, k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z));
+    BY_FIELD(k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z), (unsigned)parties);  // the kernel loops over the parties
     return ShareSuccess;
 }
 #define TYPED_PAIR(T, REQ, PFX)                                                                                          \

@@ -98,24 +98,28 @@ __global__ __launch_bounds__(256) void k_beaver_open(const uint32_t* __restrict_
     F::store_loose(d_sh + i * F::EW, F::template sub<2>(F::load(a + i * F::EW), F::load(x + i * F::EW)));
     F::store_loose(e_sh + i * F::EW, F::template sub<2>(F::load(b + i * F::EW), F::load(y + i * F::EW)));
 }
-// multiplication.rs:57-100 finalize_mul:  z = c - d*e - d*y - e*x
+// multiplication.rs:57-100 finalize_mul:  z = c - d*e - d*y - e*x  =  c - d*(e + [y]) - e*[x]
+// d, e are public (the opened values, [N]); c, x, y, z are [party][N].  One thread serves element i of EVERY party: the
+// Montgomery forms of d and e are formed once and each party costs two products (the literal form costs five per party
+// -- two conversions and d*e again for every party -- and left the kernel on the vector ALU at 3.7 TB/s).
 template <class F>
 __global__ __launch_bounds__(256) void k_beaver_finalize(const uint32_t* __restrict__ c, const uint32_t* __restrict__ x,
                                                          const uint32_t* __restrict__ y, const uint32_t* __restrict__ d,
                                                          const uint32_t* __restrict__ e, size_t N, ElemConsts cs,
-                                                         uint32_t* __restrict__ z) {
+                                                         uint32_t* __restrict__ z, unsigned parties) {
     using E = typename F::E;
-    HB_GID
-    const E dv = F::load(d + i * F::EW), ev = F::load(e + i * F::EW);
-    const E dm = F::mulc(dv, cs.r2), em = F::mulc(ev, cs.r2);  // Montgomery forms, normalised, < 2r
-    const E de = F::mont(ev, dm);                              // d*e
-    HB_PID
-    const E dy = F::mont(F::load(y + ip * F::EW), dm);             // d*[y]
-    const E ex = F::mont(F::load(x + ip * F::EW), em);             // e*[x]
-    E acc = F::template sub<4>(F::load(c + ip * F::EW), de);
-    acc = F::template sub<4>(acc, dy);
-    acc = F::template sub<4>(acc, ex);  // < 13 r, limbs < 2^29 + 3*2^30
-    F::store_loose(z + ip * F::EW, acc);
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const E ev = F::load(e + i * F::EW);
+    const E dm = F::mulc(F::load(d + i * F::EW), cs.r2), em = F::mulc(ev, cs.r2);  // Montgomery forms, normalised, < 2r
+    for (unsigned p = 0; p < parties; ++p) {
+        const size_t ip = (size_t)p * N + i;
+        const E dey = F::mont(F::add(ev, F::load(y + ip * F::EW)), dm);  // d*(e + [y]); the lazy sum is a legal first operand
+        const E ex = F::mont(F::load(x + ip * F::EW), em);               // e*[x]
+        E acc = F::template sub<4>(F::load(c + ip * F::EW), dey);
+        acc = F::template sub<4>(acc, ex);  // < 9 r
+        F::store_loose(z + ip * F::EW, acc);
+    }
 }
 // fpmul/truncpr.rs:277-283:  r_dash[i] = sum_{j<m} 2^j * r_bits[j][i];  pow2[j] = 2^j device-constant form
 template <class F>
