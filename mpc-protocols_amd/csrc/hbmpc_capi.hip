@@ -1084,7 +1084,9 @@ static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const v
     ELEM_PROLOGUE
     CHECK_PARTIES(parties);
     const ElemConsts cs = elem_consts(ctx->impl);
-    BY_FIELD(k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z), (unsigned)parties);  // the kernel loops over the parties
+    // the kernel loops over the parties (large N: the public operands are converted once per element) or spreads them
+    // over gridDim.y (small N: latency)
+    BY_FIELD_P(N >= ((size_t)1 << 16) ? 1 : parties, k_beaver_finalize, W(c), W(x), W(y), W(d), W(e), N, cs, WO(z), (unsigned)parties);
     return ShareSuccess;
 }
 #define TYPED_PAIR(T, REQ, PFX)                                                                                          \

@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void k_beaver_finalize(const uint32_t* __restr
     if (i >= N) return;
     const E ev = F::load(e + i * F::EW);
     const E dm = F::mulc(F::load(d + i * F::EW), cs.r2), em = F::mulc(ev, cs.r2);  // Montgomery forms, normalised, < 2r
-    for (unsigned p = 0; p < parties; ++p) {
+    // gridDim.y = 1: this thread serves every party (large N); gridDim.y = parties: one party each (small N, where sixteen
+    // dependent load -> multiply -> store rounds in one thread are latency the chip has idle lanes to hide)
+    for (unsigned p = blockIdx.y; p < parties; p += gridDim.y) {
         const size_t ip = (size_t)p * N + i;
         const E dey = F::mont(F::add(ev, F::load(y + ip * F::EW)), dm);  // d*(e + [y]); the lazy sum is a legal first operand
         const E ex = F::mont(F::load(x + ip * F::EW), em);               // e*[x]
