@@ -1061,6 +1061,15 @@ static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const voi
             return ShareSuccess;
         }
     }
+    if (ctx->impl == IMPL_GOLD && size <= 16 && !ctx->force_generic) {
+        const uint32_t* tw;
+        ShareErrorCode rc = get_table(ctx, key("tw", {size}, ctx->impl), [&] { return build_twiddles<HGl>(size, ctx->impl); }, &tw);
+        if (rc != ShareSuccess) return rc;
+        if (launch_fft1_triple_gold(ilog2(size), (int)dp1, W(a), W(b), W(r2t), G, (int)n, tw, EvalOut{WO(y), 0, (unsigned)parties}, s)) {
+            HIP_TRY(ctx, hipGetLastError());
+            return ShareSuccess;
+        }
+    }
     if (!tmp) return fail(ctx, InvalidInput, "no fused kernel for this shape: pass a workspace of parties * G * (d + 1) elements");
     ShareErrorCode rc = triple_local_any(ctx, a, b, r2t, parties * G * dp1, tmp, stream);
     if (rc != ShareSuccess) return rc;

@@ -21,6 +21,8 @@ bool launch_fft1_16d(int cnt, const uint32_t* x, size_t G, int n, const uint32_t
 // triple_gen's local product fused into the encode (k_eval_fft1_triple); false when the shape is not instantiated
 bool launch_fft1_triple(int lg, int cnt, const uint32_t* a, const uint32_t* b, const uint32_t* r2t, size_t G, int n,
                         const uint32_t* tw, EvalOut y, const uint32_t r2[9], hipStream_t s);
+bool launch_fft1_triple_gold(int lg, int cnt, const uint32_t* a, const uint32_t* b, const uint32_t* r2t, size_t G, int n,
+                             const uint32_t* tw, EvalOut y, hipStream_t s);
 // multi-pass (size = 16 P), U29, dp1 <= 32
 bool launch_fftP_a(int dp1, const uint32_t* x, size_t G, int n, int P, const uint32_t* tw16, const uint32_t* twist,
                    EvalOut y, hipStream_t s);

@@ -379,3 +379,34 @@ def test_in_place_wire_path_small_field(_eng):
     torch.cuda.synchronize()
     assert np.array_equal(co.cpu().numpy().view(np.uint64), x)
     assert int(stat[7]) == 1 and int(stat.sum()) == 1
+
+
+@pytest.mark.parametrize("n,t,G,parties", [(4, 1, 77, 4), (7, 2, 130, 7), (10, 3, 65, 3), (13, 4, 200, 2), (16, 5, 333, 16), (20, 6, 40, 3)])
+def test_small_field_triple_encode_fused_equals_two_launches(_eng, n, t, G, parties):
+    """hbmpc_gl_dev_triple_encode_parties: the local product fused into the encode (k_eval_fft1_triple<Gold>; (20, 6) has no
+    fused kernel and takes the workspace) against triple_local + vandermonde_apply_parties, and party 0 against big ints"""
+    import torch
+    eng = _eng
+    d = 2 * t
+    N = G * (d + 1)
+    dev = torch.device("cuda", 0)
+    a, b, r = (torch.from_numpy(rnd(70 + k, parties * N).view(np.int64)).to(dev) for k in range(3))
+    tmp = torch.empty((parties * N,), dtype=torch.int64, device=dev)
+    y1 = torch.full((parties, n, G), -1, dtype=torch.int64, device=dev)
+    y2 = torch.full((parties, n, G), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, tmp.data_ptr(), y1.data_ptr()) == 0
+    assert eng.dev_elem("triple_local", [a.data_ptr(), b.data_ptr(), r.data_ptr(), tmp.data_ptr()], parties * N) == 0
+    assert eng.dev_vandermonde_apply_parties(tmp.data_ptr(), G, n, d, parties, y2.data_ptr()) == 0
+    eng.sync()
+    assert torch.equal(y1, y2)
+    ah, bh, rh = ([int(v) for v in t_[:N].cpu().numpy().view(np.uint64)] for t_ in (a, b, r))
+    got = y1[0].cpu().numpy().view(np.uint64)
+    for g in (0, 1, G // 2, G - 1):
+        x = [(ah[g * (d + 1) + k] * bh[g * (d + 1) + k] - rh[g * (d + 1) + k]) % P for k in range(d + 1)]
+        assert [int(got[j, g]) for j in range(n)] == [s.v for s in S.compute_shares(x, n, d)]
+    if n <= 16:   # the fused kernel needs no workspace
+        y3 = torch.full_like(y1, -1)
+        assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, 0, y3.data_ptr()) == 0
+        eng.sync()
+        assert torch.equal(y3, y1)
