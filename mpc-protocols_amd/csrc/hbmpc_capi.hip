@@ -492,17 +492,22 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
         return build_mfma_table(V, dp1);
     }, &tab);
     if (*rc_out != ShareSuccess) return true;
-    a.in = (const uint8_t*)x;
     a.G = G;
     a.in_chunk_major = 1;
     a.table = (const uint8_t*)tab;
     a.nv = 0;
-    a.out = (uint8_t*)y.y;
     a.out_party_major = 1;
     a.out_stride = y.ys ? y.ys : G;
     const int mi = (int)dp1;
-    return launch_mfma_rows_a(mi, a, ctx->device, s) || launch_mfma_rows_b(mi, a, ctx->device, s) ||
-           launch_mfma_rows_c(mi, a, ctx->device, s) || launch_mfma_rows_d(mi, a, ctx->device, s);
+    // party-batched calls (x[P][G][d+1] -> y[P][n][G]): one launch per party (each is >= tens of microseconds)
+    for (unsigned p = 0; p < y.parties; ++p) {
+        a.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
+        a.out = (uint8_t*)y.y + (size_t)p * n * a.out_stride * 32;
+        if (!(launch_mfma_rows_a(mi, a, ctx->device, s) || launch_mfma_rows_b(mi, a, ctx->device, s) ||
+              launch_mfma_rows_c(mi, a, ctx->device, s) || launch_mfma_rows_d(mi, a, ctx->device, s)))
+            return false;
+    }
+    return true;
 }
 
 // the same over Goldilocks (kernels_mfma_gl.hpp): all n rows in every workgroup's LDS
@@ -526,17 +531,20 @@ static bool try_mfma_eval_gl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t
     if (*rc_out != ShareSuccess) return true;
     mf::MfmaGlArgs a;
     memset(&a, 0, sizeof a);
-    a.in = (const uint8_t*)x;
     a.G = G;
     a.in_chunk_major = 1;
     a.table = (const uint8_t*)tab;
     a.m = (int)dp1, a.nrows = (int)n, a.nv = 0;
-    a.out = (uint8_t*)y.y;
     a.out_party_major = 1;
     a.out_stride = y.ys ? y.ys : G;
     const size_t ntiles = (G + 31) / 32;
     const unsigned grid = (unsigned)std::min<size_t>((ntiles + 3) / 4, (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus * 4));
-    return launch_mfma_rows_gl(a, grid, ctx->device, s);
+    for (unsigned p = 0; p < y.parties; ++p) {  // party-batched calls: one launch per party
+        a.in = (const uint8_t*)x + (size_t)p * G * dp1 * 8;
+        a.out = (uint8_t*)y.y + (size_t)p * n * a.out_stride * 8;
+        if (!launch_mfma_rows_gl(a, grid, ctx->device, s)) return false;
+    }
+    return true;
 }
 
 static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, EvalOut y,
@@ -566,13 +574,13 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
                            : (launch_fft1_16a(c, x, G, nn, tw, y, s) || launch_fft1_16b(c, x, G, nn, tw, y, s) ||
                               launch_fft1_16c(c, x, G, nn, tw, y, s) || launch_fft1_16d(c, x, G, nn, tw, y, s))))
             return ShareSuccess;
-    } else if (impl == IMPL_U29 && ctx->matrix_cores && !ctx->force_generic && y.parties == 1 && dp1 >= 2 && dp1 <= MF_MAX_M &&
+    } else if (impl == IMPL_U29 && ctx->matrix_cores && !ctx->force_generic && y.parties <= 64 && dp1 >= 2 && dp1 <= MF_MAX_M &&
                G >= ctx->mfma_min_encode && G * dp1 * 32 < ((size_t)1 << 32) && n <= 255 &&
                try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf)) {
         // domains beyond 16 points: the dense n x (d + 1) map on the matrix cores beats the multi-pass FFT (config 3's
         // encode: 0.45 ms against 0.62 ms); up to 16 points the single-pass FFT stays (config 2: a tie at 0.187 ms)
         return rc_mf;
-    } else if (gold && ctx->matrix_cores && !ctx->force_generic && y.parties == 1 && dp1 >= 2 && dp1 <= MFGL_MAX_M &&
+    } else if (gold && ctx->matrix_cores && !ctx->force_generic && y.parties <= 64 && dp1 >= 2 && dp1 <= MFGL_MAX_M &&
                G >= ctx->mfma_min_gold && n <= 255 && try_mfma_eval_gl(ctx, x, G, n, dp1, y, s, &rc_mf)) {
         return rc_mf;
     } else if ((impl == IMPL_U29 || gold) && size <= 256 && dp1 <= 32 && !ctx->force_generic) {

@@ -296,3 +296,36 @@ def test_mid_size_decode_takes_the_matrix_cores_when_the_sender_set_recurs():
         assert e.cache_stats()["tables"] == before + 1
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("field", ["fr", "goldilocks"])
+def test_party_batched_encode_on_the_matrix_cores(field):
+    """hbmpc_[gl_]dev_vandermonde_apply_parties on a 32-point domain from 4 096 chunks on: one matrix-core launch per party;
+    every party against the single-party call and party 0 against the oracle"""
+    import torch
+    e = load_package().Engine(0, field=field)
+    try:
+        n, d, G, parties = 31, 10, 5000 + 13, 3
+        dev = torch.device("cuda", 0)
+        if field == "fr":
+            xh = rnd(91, parties, G, d + 1)
+            width = (4,)
+        else:
+            from oracle.spec_gl import P
+            rng = np.random.default_rng(5)
+            xh = (rng.integers(0, 1 << 63, (parties, G, d + 1), dtype=np.uint64) % np.uint64(P)).astype(np.uint64)
+            width = ()
+        x = torch.from_numpy(xh.view(np.int64)).to(dev)
+        y = torch.full((parties, n, G) + width, -1, dtype=torch.int64, device=dev)
+        assert e.dev_vandermonde_apply_parties(x.data_ptr(), G, n, d, parties, y.data_ptr()) == 0
+        e.sync()
+        got = y.cpu().numpy().view(np.uint64)
+        e.set_matrix_cores(False)
+        for p in range(parties):
+            rc, want = e.vandermonde_apply(xh[p], n, d)     # the FFT kernels
+            assert rc == 0 and np.array_equal(got[p], want), p
+        if field == "fr":
+            rc, want0 = O.vandermonde_apply(xh[0], n, d)
+            assert rc == 0 and np.array_equal(got[0], want0)
+    finally:
+        e.close()
