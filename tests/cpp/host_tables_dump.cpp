@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "../../mpc-protocols_amd/csrc/tables.hpp"
+#include "../../mpc-protocols_amd/csrc/tables_mfma.hpp"
+#include "../../mpc-protocols_amd/csrc/tables_mfma_gl.hpp"
 
 using namespace hbmpc;
 
@@ -56,6 +58,20 @@ static int run(size_t n, size_t d, size_t t, const std::vector<size_t>& ids) {
         }
         for (uint32_t x : T.words) std::printf(" %08x", x);
         std::printf("\n");
+    }
+    // the byte-digit tables of the matrix-core kernels (tables_mfma.hpp / tables_mfma_gl.hpp) over the decode rows of this
+    // sender set: built under the sanitizers for every shape they cover, printed for the small ones
+    if (m >= 2 && m <= (std::is_same<H, HGl>::value ? MFGL_MAX_M : MF_MAX_M)) {
+        const auto rows = recover_coeff_rows<H>(ids, n, d, t);
+        std::vector<uint32_t> tab;
+        if constexpr (std::is_same<H, HGl>::value) tab = build_mfma_table_gl(rows, m);
+        else tab = build_mfma_table(rows, m);
+        std::printf("mfma_bytes %zu\n", tab.size() * 4);
+        if (tab.size() * 4 <= 65536) {
+            std::printf("mfma");
+            for (uint32_t x : tab) std::printf(" %08x", x);
+            std::printf("\n");
+        }
     }
     return 0;
 }

@@ -96,3 +96,70 @@ def test_tables_match_oracle(dump, field, n, d, t, ids):
             want += [S.p_eval(wb[i], S.domain_element(n, ids[s])) for i in range(m)]
         want += [wb[i][k] for k in range(m) for i in range(m)]
     assert vals == want
+
+
+def _row_of_digit(b):
+    h, reg = b >> 4, b & 15
+    return (reg & 3) + 8 * (reg >> 2) + 4 * h
+
+
+@pytest.mark.parametrize("field", ["fr", "gl"])
+@pytest.mark.parametrize("n,d,t,ids", [(4, 1, 1, [3, 0, 2, 1]), (7, 2, 2, [6, 5, 4, 3, 2]), (10, 3, 3, list(range(10))),
+                                       (16, 5, 5, list(range(16))), (31, 10, 10, list(range(31)))])
+def test_matrix_core_tables(dump, field, n, d, t, ids):
+    """the byte-digit tables of the matrix-core kernels: every slab entry is a balanced digit of c * 256^a mod p for the
+    coefficient c the oracle computes, and the accumulator bias is 128 * (sum of the row's entries) plus a multiple of p
+    (tables_mfma.hpp, tables_mfma_gl.hpp).  Small shapes are checked digit by digit, the others are built under the
+    sanitizers."""
+    S = SFR if field == "fr" else SGL
+    P = S.R_MOD
+    o = dump(field, n, d, t, ids)
+    m, needed = d + 1, d + t + 1
+    assert "mfma_bytes" in o
+    if "mfma" not in o:
+        return
+    raw = b"".join(int(w, 16).to_bytes(4, "little") for w in o["mfma"][0].split())
+    sid = ids   # the dump tool takes the ids in the order given (the library sorts before it builds)
+    xs = [S.domain_element(n, i) for i in sid[:m]]
+    basis = []
+    for i in range(m):
+        co = S.lagrange_interpolate(xs, [1 if j == i else 0 for j in range(m)])
+        basis.append(co + [0] * (m - len(co)))
+    rows = [[S.p_eval(basis[i], S.domain_element(n, sid[s])) for i in range(m)] for s in range(m, needed)]
+    rows += [[basis[i][k] for i in range(m)] for k in range(m)]
+    sb = lambda v: v - 256 if v >= 128 else v   # noqa: E731
+    if field == "fr":
+        RB = m * 1024 + 128
+        assert len(raw) == len(rows) * RB
+        for r, row in enumerate(rows):
+            tsum = 0
+            for i, c in enumerate(row):
+                for a in range(32):
+                    T = sum(sb(raw[r * RB + i * 1024 + (_row_of_digit(b) + 32 * (a >> 4)) * 16 + (a & 15)]) << (8 * b) for b in range(32))
+                    assert T % P == c * pow(256, a, P) % P, (r, i, a)
+                    tsum += T
+            bias = [int.from_bytes(raw[r * RB + m * 1024 + 4 * b: r * RB + m * 1024 + 4 * b + 4], "little", signed=True) for b in range(32)]
+            assert all(0 < v < (1 << 23) for v in bias)
+            assert (sum(v << (8 * b) for b, v in enumerate(bias)) - 128 * tsum) % P == 0, r
+    else:
+        KS = (8 * m + 31) // 32
+        TR = KS * 1024 + 128
+        assert len(raw) == ((len(rows) + 3) // 4) * TR
+        for r, row in enumerate(rows):
+            mt, h, el = r // 4, (r % 4) // 2, r % 2
+            tsum = 0
+            for i, c in enumerate(row):
+                for a in range(8):
+                    kk = 8 * i + a
+                    s_, ha, j = kk // 32, (kk % 32) // 16, kk % 16
+                    T = 0
+                    for b in range(8):
+                        reg = 8 * el + b
+                        mrow = (reg & 3) + 8 * (reg >> 2) + 4 * h
+                        T += sb(raw[mt * TR + s_ * 1024 + (mrow + 32 * ha) * 16 + j]) << (8 * b)
+                    assert T % P == c * pow(256, a, P) % P, (r, i, a)
+                    tsum += T
+            off = mt * TR + KS * 1024 + (h * 16 + 8 * el) * 4
+            bias = [int.from_bytes(raw[off + 4 * b: off + 4 * b + 4], "little", signed=True) for b in range(8)]
+            assert all(0 < v < (1 << 23) for v in bias)
+            assert (sum(v << (8 * b) for b, v in enumerate(bias)) - 128 * tsum) % P == 0, r
