@@ -164,8 +164,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     if (rho < a.nv) {
                         const uint64_t val = e == 0 ? v0 : v1;
                         uint2 ys;
-                        if (mt < YT) ys = mt == 0 ? in.ys[0][e] : mt == 1 ? in.ys[1 % (YT > 0 ? YT : 1)][e] : mt == 2 ? in.ys[2 % (YT > 0 ? YT : 1)][e] : in.ys[3 % (YT > 0 ? YT : 1)][e];  // mt is uniform
-                        else ys = *reinterpret_cast<const uint2*>(a.in + (rowoff[a.m + rho] + g * 8));
+                        if (mt < YT) {  // prefetched with the inputs; mt is uniform, so this is a scalar select per register
+                            ys = in.ys[0][e];
+#pragma unroll
+                            for (int q = 1; q < YT; ++q)
+                                if (mt == q) ys = in.ys[q][e];
+                        } else {
+                            ys = *reinterpret_cast<const uint2*>(a.in + (rowoff[a.m + rho] + g * 8));
+                        }
                         bad = bad || (uint32_t)val != ys.x || (uint32_t)(val >> 32) != ys.y;
                     }
                 }
