@@ -509,7 +509,9 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * verify rows that fit one CU's LDS) run the verify and coefficient rows on the matrix cores: every row is a constant
  * vector (a function of n, d, t and the sender ids) times batch data, i.e. an int8 GEMM over the bytes of the canonical
  * elements followed by one carry pass and one small-quotient reduction (csrc/kernels_mfma.hpp).  Results are
- * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both).
+ * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both); on = 2
+ * keeps the matrix cores but not the workgroup-per-tile kernel that batches with fewer 32-chunk tiles than waves take
+ * (up to 16 384 chunks on a 256-CU chip: a tile's rows are shared by the waves of a workgroup instead of walked by one wave).
  * A Goldilocks context has the same switch: its decodes and its encodes on domains beyond 16 points run on the matrix
  * cores from 4 096 chunks for 2 <= d + 1 <= 16 (csrc/kernels_mfma_gl.hpp: the table is a few KB, fits the LDS whole and
  * costs microseconds to build, so there is no sender-set rule).

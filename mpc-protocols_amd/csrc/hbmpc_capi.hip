@@ -56,6 +56,7 @@ struct hbmpc_ctx {
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
     size_t mfma_min_cached = 6144;                 // ... and from this many when the sender set's table is cached or the set recurs
     size_t mfma_min_encode = 4096;                 // encodes (one table per (n, d), never rebuilt): from this many chunks
+    bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
     size_t mfma_min_gold = 4096;                   // Goldilocks (tiny tables, one workgroup kind): from this many chunks
     std::map<std::string, int> mfma_seen;          // sender sets of mid-size decodes that went to the lane kernels, by sightings
     int n_cus = 256;
@@ -283,6 +284,7 @@ extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
 extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks) {  // either field
     if (!ctx) return InvalidInput;
     ctx->matrix_cores = on != 0;
+    ctx->mfma_team = on != 2;  // 2: without the workgroup-per-tile kernel of small batches (A/B aid)
     if (min_chunks) {
         ctx->mfma_min_gold = std::min<size_t>(min_chunks, 4096);
         ctx->mfma_min_chunks = min_chunks;

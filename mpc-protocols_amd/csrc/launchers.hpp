@@ -48,13 +48,14 @@ bool launch_recover_b(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipS
 bool launch_recover_c(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
-// matrix-core form of the constant-matrix maps (kernels_mfma.hpp), m = 2 .. 15; false when m is not instantiated there
+// matrix-core form of the constant-matrix maps (kernels_mfma.hpp), m = 2 .. 15; false when m is not instantiated there.
+// team: the workgroup-per-tile form for batches with fewer tiles than waves (kernels_mfma_team.hpp)
 namespace mf { struct MfmaRowsArgs; struct MfmaGlArgs; }
 bool launch_mfma_rows_gl(const mf::MfmaGlArgs& a, unsigned grid, int device, hipStream_t s);  // Goldilocks (kernels_mfma_gl.hpp)
-bool launch_mfma_rows_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
-bool launch_mfma_rows_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
-bool launch_mfma_rows_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
-bool launch_mfma_rows_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
+bool launch_mfma_rows_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
+bool launch_mfma_rows_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
+bool launch_mfma_rows_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
+bool launch_mfma_rows_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 // small batches: one wave per chunk, one evaluation point / one table row per lane (k_eval_wide, k_batch_recover_wide)
 void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s);
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);

@@ -127,7 +127,8 @@ class Engine:
 
     def set_matrix_cores(self, on: bool, min_chunks: int = 0):
         """large Fr decodes on the matrix cores (int8 MFMA); min_chunks = 0 keeps the current threshold"""
-        assert self.L.hbmpc_set_matrix_cores(self.ctx, C.c_int(1 if on else 0), C.c_size_t(min_chunks)) == 0
+        # on: False / True, or 2 = matrix cores without the workgroup-per-tile kernel of small batches (A/B)
+        assert self.L.hbmpc_set_matrix_cores(self.ctx, C.c_int(int(on)), C.c_size_t(min_chunks)) == 0
 
     def scrub_staging(self):
         assert self.L.hbmpc_scrub_staging(self.ctx) == 0

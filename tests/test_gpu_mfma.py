@@ -43,6 +43,9 @@ def both_ways(eng, ids, ev, n, d, t, p0=False):
     call = eng.batch_recover_p0 if p0 else eng.batch_recover
     eng.set_matrix_cores(True, 1)
     a = call(ids, ev, n, d, t)
+    eng.set_matrix_cores(2, 1)               # without the workgroup-per-tile kernel that small batches take
+    a2 = call(ids, ev, n, d, t)
+    assert a[0] == a2[0] and all(np.array_equal(u, v) for u, v in zip(a[1:], a2[1:]))
     eng.set_matrix_cores(False)
     b = call(ids, ev, n, d, t)
     eng.set_matrix_cores(True, 65536)
