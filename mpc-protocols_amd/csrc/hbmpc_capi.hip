@@ -55,6 +55,7 @@ struct hbmpc_ctx {
     bool matrix_cores = true;                      // large Fr decodes run the int8 MFMA formulation (kernels_mfma.hpp)
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
     size_t mfma_min_cached = 6144;                 // ... and from this many when the sender set's table is cached or the set recurs
+    size_t mfma_min_direct = 2048;                 // ... and from this many when the call has no OEC round (one launch)
     size_t mfma_min_encode = 4096;                 // encodes (one table per (n, d), never rebuilt): from this many chunks
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
     size_t mfma_min_gold = 4096;                   // Goldilocks (tiny tables, one workgroup kind): from this many chunks
@@ -289,6 +290,7 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
         ctx->mfma_min_gold = std::min<size_t>(min_chunks, 4096);
         ctx->mfma_min_chunks = min_chunks;
         ctx->mfma_min_cached = std::min<size_t>(min_chunks, 6144);
+        ctx->mfma_min_direct = std::min<size_t>(min_chunks, 2048);
         ctx->mfma_min_encode = std::min<size_t>(min_chunks, 4096);
     }
     return ShareSuccess;

@@ -106,12 +106,20 @@ HB_DEV void count_failures(bool bad, size_t g, uint32_t* counters) {
         __threadfence();  // performed before this block takes its ticket
     }
 }
-// every thread of every block, at the end of a direct kernel
+// every thread of every block, at the end of a direct kernel.  The ticket is two-level (16 sub-tickets in counters[8..24),
+// then counters[3]): thousands of blocks taking one ticket word serialise on it -- 2048 blocks of the wave-per-chunk
+// kernel added 11 us to a 20 us call.
+constexpr unsigned DIRECT_FAN = 16;
 HB_DEV void finish_direct(uint32_t* counters, uint32_t* summary) {
     __syncthreads();
     if (threadIdx.x != 0) return;
-    const unsigned nblocks = gridDim.x * gridDim.y;
-    if (atomicAdd(counters + 3, 1u) != nblocks - 1) return;
+    const unsigned nblocks = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+    const unsigned sub = b % DIRECT_FAN, quota = nblocks / DIRECT_FAN + (sub < nblocks % DIRECT_FAN ? 1u : 0u);  // blocks with this residue
+    if (atomicAdd(counters + 8 + sub, 1u) != quota - 1) return;
+    const unsigned groups = nblocks < DIRECT_FAN ? nblocks : DIRECT_FAN;
+    if (atomicAdd(counters + 3, 1u) != groups - 1) return;
+#pragma unroll
+    for (unsigned k = 0; k < DIRECT_FAN; ++k) store_handoff(counters + 8 + k, 0u);
     const uint32_t failed = load_handoff(counters), low = load_handoff(counters + 1);
     if (summary) {
         summary[0] = failed, summary[1] = failed;
