@@ -512,9 +512,10 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both); on = 2
  * keeps the matrix cores but not the workgroup-per-tile kernel that batches with fewer 32-chunk tiles than waves take
  * (up to 16 384 chunks on a 256-CU chip: a tile's rows are shared by the waves of a workgroup instead of walked by one wave).
- * A Goldilocks context has the same switch: its decodes and its encodes on domains beyond 16 points run on the matrix
- * cores from 4 096 chunks for 2 <= d + 1 <= 16 (csrc/kernels_mfma_gl.hpp: the table is a few KB, fits the LDS whole and
- * costs microseconds to build, so there is no sender-set rule).
+ * A Goldilocks context has the same switch: for 2 <= d + 1 <= 16 its encodes on domains beyond 16 points run on the
+ * matrix cores from 4 096 chunks, its decodes from 2 048 chunks when they are a single launch (exactly d + t + 1 senders)
+ * and beyond the small-batch range (8 192 chunks) otherwise (csrc/kernels_mfma_gl.hpp: the table is a few KB, fits the
+ * LDS whole and costs microseconds to build, so there is no sender-set rule).
  * min_chunks = 0 keeps the current thresholds.  Defaults: a decode of >= 65 536 chunks always takes the path (a sender
  * set not seen before costs ~0.7 ms of host table construction, more than a smaller call saves); a decode of
  * 6 144 .. 65 535 chunks -- from 2 048 when it is given exactly d + t + 1 senders, i.e. is a single launch -- takes it

@@ -58,7 +58,9 @@ struct hbmpc_ctx {
     size_t mfma_min_direct = 2048;                 // ... and from this many when the call has no OEC round (one launch)
     size_t mfma_min_encode = 4096;                 // encodes (one table per (n, d), never rebuilt): from this many chunks
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
-    size_t mfma_min_gold = 4096;                   // Goldilocks (tiny tables, one workgroup kind): from this many chunks
+    size_t mfma_min_gold = 4096;                   // Goldilocks encodes (tiny tables, one workgroup kind): from this many chunks
+    size_t mfma_min_gold_direct = 2048;            // Goldilocks decodes without OEC rounds (one launch): flat ~7 us against a wave-per-chunk kernel that grows
+    size_t mfma_min_gold_oec = 8193;               // Goldilocks decodes with OEC rounds (four launches against the small-batch path's two): beyond its range
     std::map<std::string, int> mfma_seen;          // sender sets of mid-size decodes that went to the lane kernels, by sightings
     int n_cus = 256;
     int mfma_wgs = 0;                              // test aid: workgroups of a matrix-core launch (0 = one per CU)
@@ -288,6 +290,8 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
     ctx->mfma_team = on != 2;  // 2: without the workgroup-per-tile kernel of small batches (A/B aid)
     if (min_chunks) {
         ctx->mfma_min_gold = std::min<size_t>(min_chunks, 4096);
+        ctx->mfma_min_gold_direct = std::min<size_t>(min_chunks, 2048);
+        ctx->mfma_min_gold_oec = std::min<size_t>(min_chunks, 8193);
         ctx->mfma_min_chunks = min_chunks;
         ctx->mfma_min_cached = std::min<size_t>(min_chunks, 6144);
         ctx->mfma_min_direct = std::min<size_t>(min_chunks, 2048);
