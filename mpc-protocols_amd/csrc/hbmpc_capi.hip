@@ -54,9 +54,9 @@ struct hbmpc_ctx {
     bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
     bool matrix_cores = true;                      // large Fr decodes run the int8 MFMA formulation (kernels_mfma.hpp)
     size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
-    size_t mfma_min_cached = 6144;                 // ... and from this many when the sender set's table is cached or the set recurs
+    size_t mfma_min_cached = 4096;                 // ... and from this many when the sender set's table is cached or the set recurs
     size_t mfma_min_direct = 2048;                 // ... and from this many when the call has no OEC round (one launch)
-    size_t mfma_min_encode = 4096;                 // encodes (one table per (n, d), never rebuilt): from this many chunks
+    size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
     size_t mfma_min_gold = 4096;                   // Goldilocks encodes (tiny tables, one workgroup kind): from this many chunks
     size_t mfma_min_gold_direct = 2048;            // Goldilocks decodes without OEC rounds (one launch): flat ~7 us against a wave-per-chunk kernel that grows
@@ -293,9 +293,9 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
         ctx->mfma_min_gold_direct = std::min<size_t>(min_chunks, 2048);
         ctx->mfma_min_gold_oec = std::min<size_t>(min_chunks, 8193);
         ctx->mfma_min_chunks = min_chunks;
-        ctx->mfma_min_cached = std::min<size_t>(min_chunks, 6144);
+        ctx->mfma_min_cached = std::min<size_t>(min_chunks, 4096);
         ctx->mfma_min_direct = std::min<size_t>(min_chunks, 2048);
-        ctx->mfma_min_encode = std::min<size_t>(min_chunks, 4096);
+        ctx->mfma_min_encode = std::min<size_t>(min_chunks, 2049);
     }
     return ShareSuccess;
 }
@@ -485,7 +485,16 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
     const size_t rowb = mf_row_bytes(dp1);
     mf::MfmaRowsArgs a;
     memset(&a, 0, sizeof a);
-    if (!mf::mf_plan_roles((int)n, 0, (int)((160 * 1024) / rowb), ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus, &a)) return false;
+    // up to two tiles per workgroup: the workgroup-per-tile kernel (kernels_mfma_team.hpp; no verify rows here, so no barriers)
+    const int nwg = ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus;
+    // (measured, 4 096 .. 16 384 chunks: n = 20, d = 6: 6.7 .. 10.0 us against 19 .. 20; n = 31, d = 10 -- three roles --
+    // 9.8 and 15.1 us against 17.6 and 18.2 at 4 096 and 8 192 chunks, behind at 16 384)
+    bool team = ctx->mfma_team && (G + 31) / 32 <= (size_t)nwg * 2;
+    if (!mf::mf_plan_roles((int)n, 0, (int)((160 * 1024 - (team ? 128 : 0)) / rowb), nwg, &a)) return false;
+    if (team && a.nroles > 1 && (G + 31) / 32 > (size_t)nwg) {
+        team = false;
+        if (!mf::mf_plan_roles((int)n, 0, (int)((160 * 1024) / rowb), nwg, &a)) return false;
+    }
     const uint32_t* tab;
     *rc_out = get_table(ctx, key("mfvand", {n, dp1}, ctx->impl), [&] {
         std::vector<HFr> el = domain_elements<HFr>(n, n);
@@ -511,8 +520,8 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
     for (unsigned p = 0; p < y.parties; ++p) {
         a.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
         a.out = (uint8_t*)y.y + (size_t)p * n * a.out_stride * 32;
-        if (!(launch_mfma_rows_a(mi, a, ctx->device, s) || launch_mfma_rows_b(mi, a, ctx->device, s) ||
-              launch_mfma_rows_c(mi, a, ctx->device, s) || launch_mfma_rows_d(mi, a, ctx->device, s)))
+        if (!(launch_mfma_rows_a(mi, a, ctx->device, s, team) || launch_mfma_rows_b(mi, a, ctx->device, s, team) ||
+              launch_mfma_rows_c(mi, a, ctx->device, s, team) || launch_mfma_rows_d(mi, a, ctx->device, s, team)))
             return false;
     }
     return true;

@@ -258,7 +258,7 @@ def test_full_size_config3_encode(eng):
 
 
 def test_mid_size_decode_takes_the_matrix_cores_when_the_sender_set_recurs():
-    """default thresholds (hbmpc_set_matrix_cores doc): a 6 144 .. 65 535-chunk decode stays with the lane kernels the
+    """default thresholds (hbmpc_set_matrix_cores doc): a 4 096 .. 65 535-chunk decode stays with the lane kernels the
     first time a sender set is seen, builds the matrix-core table the second time and uses it from then on; a >= 4 096-chunk
     encode on a 32-point domain takes the matrix cores at once.  Same bytes whichever kernel ran."""
     e = load_package().Engine(0)
