@@ -108,11 +108,12 @@ def test_one_launch_equals_oracle_and_two_launches(family, n, d, t, G, p0):
         e.close()
 
 
-def test_every_chunk_fails():
+@pytest.mark.parametrize("G", [5000, 50000])   # workgroup per tile / wave per tile on the matrix cores
+def test_every_chunk_fails(G):
     """the failure path is as parallel as the decode: a batch in which EVERY chunk fails"""
     e = load_package().Engine(0)
     try:
-        n, d, t, G = 16, 5, 5, 50000
+        n, d, t = 16, 5, 5
         ids, ev = make(9, G, n, d, t, [])
         ev[d + 2] ^= np.uint64(1)              # one verify row wrong everywhere
         for mf in (False, True):
