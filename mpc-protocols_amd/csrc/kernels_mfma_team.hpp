@@ -6,7 +6,7 @@
 // owns the tile and its waves share the rows (row r of the role goes to wave r mod WAVES): a tile costs one or two rows of
 // latency, every workgroup of the launch has work, and the price -- each wave loads the tile's inputs for itself, out of
 // the L2 -- is nothing at these sizes.  The verify verdict of a tile is the OR over the waves, through 32 flag words in
-// LDS and two barriers.  Same tables, same row arithmetic (kernels_mfma.hpp), same roles, same hand-off to the fallback
+// LDS (one barrier before they are read, two around their reset; roles without verify rows -- every encode -- have none).  Same tables, same row arithmetic (kernels_mfma.hpp), same roles, same hand-off to the fallback
 // kernels; results are bit-identical.
 #pragma once
 #include "kernels_mfma.hpp"
