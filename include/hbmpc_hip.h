@@ -520,8 +520,9 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * set not seen before costs ~0.7 ms of host table construction, more than a smaller call saves); a decode of
  * 4 096 .. 65 535 chunks -- from 2 048 when it is given exactly d + t + 1 senders, i.e. is a single launch -- takes it
  * when the sender set's table is already cached, and builds it the SECOND time the set is seen (a set seen once stays
- * with the lane kernels); evaluations on domains beyond 16 points (one table per
- * (n, d), never rebuilt) take it from 2 049 chunks, i.e. right above the wave-per-chunk kernel's range.  A nonzero min_chunks sets the first threshold and caps the other
+ * with the lane kernels); evaluations (one table per (n, d), never rebuilt) take it from
+ * 2 049 chunks, i.e. right above the wave-per-chunk kernel's range -- on domains beyond 16 points at every size, on
+ * smaller domains while a workgroup has at most two tiles (16 384 chunks on 256 CUs; beyond that the single-pass FFT).  A nonzero min_chunks sets the first threshold and caps the other
  * two at it -- e.g. (1, 4096) before the eager run that precedes a graph capture makes mid-size decodes build their
  * table at once (nothing can be built during capture: a call whose table is missing then records the lane kernels). */
 ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);

@@ -579,6 +579,13 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
         launch_eval_wide(impl, x, G, (int)n, (int)dp1, alpha, y, s);
         return ShareSuccess;
     }
+    // mid-size batches on small domains as well: up to two tiles per workgroup the workgroup-per-tile matrix-core kernel
+    // beats the single-pass FFT on latency -- n = 16, d = 5: 5.8 us against 12.3 us at 2 100 .. 4 096 chunks, 8.4 against
+    // 13.3 at 16 384 (profiles/r02_team_kernel_encode.txt); at 2^20 the two tie
+    if (impl == IMPL_U29 && size <= 16 && ctx->matrix_cores && ctx->mfma_team && !ctx->force_generic && y.parties == 1 && dp1 >= 2 &&
+        dp1 <= MF_MAX_M && G >= ctx->mfma_min_encode && (G + 31) / 32 <= (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
+        try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf))
+        return rc_mf;
     if ((impl == IMPL_U29 || gold) && size <= 16 && !ctx->force_generic) {
         const uint32_t* tw;
         ShareErrorCode rc = get_table(ctx, key("tw", {size}, impl), [&] {

@@ -332,3 +332,23 @@ def test_party_batched_encode_on_the_matrix_cores(field):
             assert rc == 0 and np.array_equal(got[0], want0)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("n,d,G", [(16, 5, 5000 + 3), (16, 10, 9000 + 1), (7, 2, 3000 + 7), (10, 3, 2049), (16, 5, 16384), (13, 4, 4096)])
+def test_mid_size_encode_on_small_domains(n, d, G):
+    """default thresholds: on domains up to 16 points a 2 049 .. 16 384-chunk encode (compute_shares, apply_vandermonde) takes
+    the workgroup-per-tile matrix-core kernel instead of the single-pass FFT; same bytes as the FFT kernels and the oracle"""
+    e = load_package().Engine(0)
+    try:
+        x = rnd(300 + n + d, G, d + 1)
+        x[0] = 0
+        x[1] = O.ints_to_u256([O_R - 1] * (d + 1))
+        rc, y = e.vandermonde_apply(x, n, d)
+        rc2, y2 = e.compute_shares(x, n, d)
+        e.set_matrix_cores(False)
+        rc3, y3 = e.vandermonde_apply(x, n, d)
+        rc0, want = O.vandermonde_apply(x, n, d)
+        assert rc == rc2 == rc3 == rc0 == 0
+        assert np.array_equal(y, want) and np.array_equal(y2, want) and np.array_equal(y3, want)
+    finally:
+        e.close()
