@@ -56,8 +56,12 @@ class CapturablePipeline {
   public:
     virtual ~CapturablePipeline() { hbmpc_graph_destroy(graph_); }
     virtual void run() = 0;  // enqueue only
-    void capture() {         // one eager run so that tables and scratch exist, then record the same calls
+    // Two eager runs, then the same calls are recorded: nothing can be built during capture, and a mid-size decode builds
+    // its matrix-core table the second time it sees a sender set (hbmpc_set_matrix_cores) -- the recorded launches are then
+    // the ones an eager caller gets from its second call on.
+    void capture() {
         if (!stream_) throw std::runtime_error("capture needs an explicit stream");
+        run();
         run();
         pl_check(hbmpc_stream_sync(ctx_, stream_), ctx_, "sync");
         pl_check(hbmpc_graph_begin_capture(ctx_, stream_), ctx_, "begin_capture");

@@ -55,6 +55,10 @@ class _Capturable:
 
     def capture(self):
         assert self.stream, "capture needs an explicit stream"
+        # two eager runs: nothing can be built during capture, and a mid-size decode builds its matrix-core table the
+        # second time it sees a sender set (hbmpc_set_matrix_cores) -- the recorded launches are then the ones an eager
+        # caller gets from its second call on
+        self.run(check=False)
         self.run(check=False)
         self.eng.sync(self.stream)
         self.eng.graph_begin(self.stream)
