@@ -740,6 +740,18 @@ def pipeline_measurements(eng, torch, dev, stream, ev_time):
     res["cfg5_fpmul_small_batch"] = {"elements": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
                                      "fpmuls_per_s_hip_graph": Ns / ms_graph * 1e3}
     fp.close()
+    # in between: 8192 elements -- each of the three opens is ONE matrix-core launch (workgroup per tile) once its sender
+    # set has been seen twice
+    Nm = 8192
+    fp = setup_fpmul(eng, torch, dev, stream, n, t, Nm, k, m)
+    fp.run(check=True)
+    fp.run(check=False)
+    ms_eager = ev_time(lambda: fp.run(check=False), reps=20, warm=2)
+    fp.capture()
+    ms_graph = ev_time(fp.replay, reps=20, warm=2)
+    res["cfg5_fpmul_mid_batch"] = {"elements": Nm, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
+                                   "fpmuls_per_s_hip_graph": Nm / ms_graph * 1e3}
+    fp.close()
     return res
 
 
