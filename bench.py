@@ -472,11 +472,15 @@ def extra_measurements(eng, torch, dev, stream):
             fn()
             torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gc_on = gc.isenabled()
+        gc.disable()  # a full collection (~40 ms with torch imported) inside a 20-launch loop reads as a 4x slower row
         e0.record()
         for _ in range(reps):
             fn()
         e1.record()
         torch.cuda.synchronize()
+        if gc_on:
+            gc.enable()
         return e0.elapsed_time(e1) / reps
 
     # config 3: n=31, t=10, d=10, 2^20 chunks: encode (apply_vandermonde) and decode (batch_recover_secret)

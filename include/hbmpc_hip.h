@@ -322,6 +322,12 @@ ShareErrorCode hbmpc_dev_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const
                                             const U256* y, size_t N, U256* d_sh_out, U256* e_sh_out, void* stream);
 ShareErrorCode hbmpc_dev_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d,
                                          const U256* e, size_t N, U256* z_out, void* stream);
+/* beaver_open_shares for `parties` parties at once (a, b, x, y: [party][N]) with a party's two results side by side:
+ * de_sh_out[party][0][N] = a - x, [party][1][N] = b - y.  One robust interpolation over 2 N values per sender
+ * (hbmpc_dev_batch_recover_p0 with G = 2 N: the sender rows are the parties' rows of de_sh_out) then opens d and e
+ * together -- one call instead of two; its output is d[N] followed by e[N]. */
+ShareErrorCode hbmpc_dev_beaver_open_shares_paired(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x, const U256* y,
+                                                   size_t N, size_t parties, U256* de_sh_out, void* stream);
 ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, U256* r_dash_out,
                                        void* stream);
 ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* r_int,
@@ -501,6 +507,9 @@ ShareErrorCode hbmpc_gl_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, const
                                         const uint64_t* d, const uint64_t* e, size_t N, uint64_t* z_out);
 ShareErrorCode hbmpc_gl_dev_beaver_finalize(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,
                                             const uint64_t* d, const uint64_t* e, size_t N, uint64_t* z_out, void* stream);
+ShareErrorCode hbmpc_gl_dev_beaver_open_shares_paired(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* x,
+                                                      const uint64_t* y, size_t N, size_t parties, uint64_t* de_sh_out,
+                                                      void* stream);
 
 /* ---- A/B aid: 0 = unsaturated 9x29-bit limbs (default, fast), 1 = saturated 8x32-bit limbs
  * (the straightforward formulation; same results, kept as a cross-check). */

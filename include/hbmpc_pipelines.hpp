@@ -150,12 +150,14 @@ class FpMul : public CapturablePipeline {
   public:
     FpMul(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, size_t k, size_t m, void* stream, size_t open_senders = 0)
         : CapturablePipeline(ctx, stream), n_(n), t_(t), N_(N), k_(k), m_(m),
-          arena_(ctx, ((12 + m) * n * N + 4 * N) * 32 + 4 * N + (1 << 14)) {
-        U256** per_party[] = {&x, &y, &ta, &tb, &tc, &rint, &dsh_, &esh_, &z, &rdash_, &osh_, &out};
+          arena_(ctx, ((12 + m) * n * N + 4 * N) * 32 + 8 * N + (1 << 14)) {
+        U256** per_party[] = {&x, &y, &ta, &tb, &tc, &rint, &z, &rdash_, &osh_, &out};
         for (U256** q : per_party) *q = arena_.take(n * N);
+        desh_ = arena_.take(2 * n * N);  // [party][2][N]: a party's shares of a - x and of b - y side by side
         rbits = arena_.take(n * m * N);  // [party][bit][N]
-        dop_ = arena_.take(N), eop_ = arena_.take(N), cop_ = arena_.take(N);
-        status_ = static_cast<uint8_t*>(arena_.take_bytes(N));
+        dop_ = arena_.take(2 * N), eop_ = dop_ + N;  // the opened a - x [N], then the opened b - y [N]
+        cop_ = arena_.take(N);
+        status_ = static_cast<uint8_t*>(arena_.take_bytes(2 * N));
         summ = static_cast<hbmpc_recover_summary*>(arena_.take_bytes(64));
         if (open_senders == 0) open_senders = 2 * t + 1;
         if (open_senders < 2 * t + 1 || open_senders > n) throw std::invalid_argument("FpMul: 2t+1 <= open_senders <= n");
@@ -164,9 +166,9 @@ class FpMul : public CapturablePipeline {
     void run() override {
         const size_t n = n_, N = N_;
         // one launch per step for all parties (the [party][N] arrays are contiguous; opened values are broadcast)
-        pl_check(hbmpc_dev_beaver_open_shares(ctx_, ta, tb, x, y, n * N, dsh_, esh_, stream_), ctx_, "beaver_open_shares");  // multiplication.rs:417-426
-        open(dsh_, dop_, "open a-x");  // reconstruct_rbc: per-element recover_secret (:102-139)
-        open(esh_, eop_, "open b-y");
+        pl_check(hbmpc_dev_beaver_open_shares_paired(ctx_, ta, tb, x, y, N, n, desh_, stream_), ctx_, "beaver_open_shares");  // multiplication.rs:417-426
+        // reconstruct_rbc: per-element recover_secret of a - x and of b - y (:102-139) -- ONE call over the 2 N values of a sender row
+        open(desh_, dop_, "open a-x, b-y", 2 * N);
         pl_check(hbmpc_dev_beaver_finalize_parties(ctx_, tc, x, y, dop_, eop_, N, n, z, stream_), ctx_, "beaver_finalize");  // :57-100
         pl_check(hbmpc_dev_truncpr_rdash_parties(ctx_, rbits, m_, N, n, rdash_, stream_), ctx_, "truncpr_rdash");  // truncpr.rs:277-283
         pl_check(hbmpc_dev_truncpr_open_share(ctx_, z, rdash_, rint, k_, m_, n * N, osh_, stream_), ctx_, "truncpr_open_share");
@@ -177,12 +179,13 @@ class FpMul : public CapturablePipeline {
     hbmpc_recover_summary* summ;
 
   private:
-    void open(const U256* shares, U256* dst, const char* what) {
-        pl_check(hbmpc_dev_batch_recover_p0(ctx_, ids_.data(), ids_.size(), shares, N_, n_, t_, t_, dst, status_, summ, stream_), ctx_, what);
+    void open(const U256* shares, U256* dst, const char* what, size_t values = 0) {
+        pl_check(hbmpc_dev_batch_recover_p0(ctx_, ids_.data(), ids_.size(), shares, values ? values : N_, n_, t_, t_, dst, status_, summ, stream_),
+                 ctx_, what);
     }
     size_t n_, t_, N_, k_, m_;
     DeviceArena arena_;
-    U256 *dsh_, *esh_, *rdash_, *osh_, *dop_, *eop_, *cop_;
+    U256 *desh_, *rdash_, *osh_, *dop_, *eop_, *cop_;
     uint8_t* status_;
     std::vector<size_t> ids_;
 };

@@ -1120,6 +1120,13 @@ static ShareErrorCode beaver_open_any(hbmpc_ctx* ctx, const void* a, const void*
     BY_FIELD(k_beaver_open, W(a), W(b), W(x), W(y), N, WO(d_sh), WO(e_sh));
     return ShareSuccess;
 }
+static ShareErrorCode beaver_open_pair_any(hbmpc_ctx* ctx, const void* a, const void* b, const void* x, const void* y, size_t N,
+                                           size_t parties, void* de, void* stream) {
+    ELEM_PROLOGUE
+    CHECK_PARTIES(parties);
+    BY_FIELD_P(parties, k_beaver_open_pair, W(a), W(b), W(x), W(y), N, WO(de));
+    return ShareSuccess;
+}
 static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const void* x, const void* y, const void* d,
                                           const void* e, size_t N, void* z, void* stream, size_t parties = 1) {
     ELEM_PROLOGUE
@@ -1170,6 +1177,12 @@ static ShareErrorCode beaver_finalize_any(hbmpc_ctx* ctx, const void* c, const v
 TYPED_PAIR(U256, REQ_FR, hbmpc_)
 TYPED_PAIR(uint64_t, REQ_GL, hbmpc_gl_)
 #define TYPED_PARTIES(T, REQ, PFX)                                                                                       \
+    extern "C" ShareErrorCode PFX##dev_beaver_open_shares_paired(hbmpc_ctx* ctx, const T* a, const T* b, const T* x,     \
+                                                                 const T* y, size_t N, size_t parties, T* de_sh_out,     \
+                                                                 void* stream) {                                         \
+        REQ(ctx);                                                                                                        \
+        return beaver_open_pair_any(ctx, a, b, x, y, N, parties, de_sh_out, stream);                                     \
+    }                                                                                                                    \
     extern "C" ShareErrorCode PFX##dev_triple_finalize_parties(hbmpc_ctx* ctx, const T* rt, const T* opened, size_t N,   \
                                                                size_t parties, T* c_out, void* stream) {                 \
         REQ(ctx);                                                                                                        \

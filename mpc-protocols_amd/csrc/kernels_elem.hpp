@@ -98,6 +98,19 @@ __global__ __launch_bounds__(256) void k_beaver_open(const uint32_t* __restrict_
     F::store_loose(d_sh + i * F::EW, F::template sub<2>(F::load(a + i * F::EW), F::load(x + i * F::EW)));
     F::store_loose(e_sh + i * F::EW, F::template sub<2>(F::load(b + i * F::EW), F::load(y + i * F::EW)));
 }
+// the same for `parties` parties at once ([party][N] inputs), with the two results of a party side by side:
+// de[party][0][N] = a - x, de[party][1][N] = b - y -- ONE robust-interpolation call over 2 N "chunks" then opens both (the
+// sender rows of that call are the parties' rows of 2 N elements), instead of two calls over N
+template <class F>
+__global__ __launch_bounds__(256) void k_beaver_open_pair(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                          const uint32_t* __restrict__ x, const uint32_t* __restrict__ y,
+                                                          size_t N, uint32_t* __restrict__ de) {
+    HB_GID
+    HB_PID
+    const size_t o = (lin_ % gridDim.y) * 2 * N + i;
+    F::store_loose(de + o * F::EW, F::template sub<2>(F::load(a + ip * F::EW), F::load(x + ip * F::EW)));
+    F::store_loose(de + (o + N) * F::EW, F::template sub<2>(F::load(b + ip * F::EW), F::load(y + ip * F::EW)));
+}
 // multiplication.rs:57-100 finalize_mul:  z = c - d*e - d*y - e*x  =  c - d*(e + [y]) - e*[x]
 // d, e are public (the opened values, [N]); c, x, y, z are [party][N].  One thread serves element i of EVERY party: the
 // Montgomery forms of d and e are formed once and each party costs two products (the literal form costs five per party

@@ -432,6 +432,11 @@ class Engine:
                [C.c_size_t(N), C.c_size_t(parties)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
         return getattr(self.L, self._pfx + "dev_" + name + "_parties")(*args)
 
+    def dev_beaver_open_shares_paired(self, a_d, b_d, x_d, y_d, N, parties, de_d, stream=0):
+        """de[party][0][N] = a - x, de[party][1][N] = b - y: one P(0) decode over 2 N values per sender opens both"""
+        return self._f("dev_beaver_open_shares_paired")(self.ctx, C.c_void_p(a_d), C.c_void_p(b_d), C.c_void_p(x_d), C.c_void_p(y_d),
+                                                          C.c_size_t(N), C.c_size_t(parties), C.c_void_p(de_d), C.c_void_p(stream))
+
     # ---- wire codec ----
     def dev_pack_fvec(self, rows_d, row_stride, G, n_rows, payloads_d, payload_stride_bytes, stream=0):
         return self.L.hbmpc_dev_pack_fvec(self.ctx, C.c_void_p(rows_d), C.c_size_t(row_stride), C.c_size_t(G),

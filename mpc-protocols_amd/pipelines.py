@@ -147,13 +147,16 @@ class FpMul(_Capturable):
         self.eng, self.n, self.t, self.N, self.k, self.m, self.stream = eng, n, t, N, k, m, stream
         self.open_senders = 2 * t + 1 if open_senders is None else open_senders
         assert 2 * t + 1 <= self.open_senders <= n
-        self.arena = DeviceArena(eng, ((12 + m) * n * N + 4 * N) * U + 4 * N + (1 << 14))
+        self.arena = DeviceArena(eng, ((12 + m) * n * N + 4 * N) * U + 8 * N + (1 << 14))
         ar = self.arena
-        (self.x, self.y, self.ta, self.tb, self.tc, self.rint, self.dsh, self.esh, self.z, self.rdash, self.osh,
-         self.out) = (ar.take(n * N * U) for _ in range(12))
+        (self.x, self.y, self.ta, self.tb, self.tc, self.rint, self.z, self.rdash, self.osh,
+         self.out) = (ar.take(n * N * U) for _ in range(10))
+        self.desh = ar.take(2 * n * N * U)    # [party][2][N]: a party's shares of a - x and of b - y side by side
         self.rbits = ar.take(n * m * N * U)   # [party][bit][N]
-        self.dop, self.eop, self.cop = (ar.take(N * U) for _ in range(3))
-        self.status = ar.take(N)
+        self.deop = ar.take(2 * N * U)        # the opened a - x [N], then the opened b - y [N]
+        self.dop, self.eop = self.deop, self.deop + N * U
+        self.cop = ar.take(N * U)
+        self.status = ar.take(2 * N)
         self.summ = ar.take(64)
 
     def upload(self, x, y, ta, tb, tc, rbits, rint):
@@ -161,8 +164,9 @@ class FpMul(_Capturable):
                          (self.rint, rint)):
             self.eng.h2d(dst, np.ascontiguousarray(src), self.stream)
 
-    def _open(self, shares, out, what):
-        e, n, t, N, s = self.eng, self.n, self.t, self.N, self.stream
+    def _open(self, shares, out, what, values=None):
+        e, n, t, s = self.eng, self.n, self.t, self.stream
+        N = self.N if values is None else values      # values per sender row
         _check(e.dev_batch_recover(list(range(self.open_senders)), shares, N, n, t, t, out, 0, self.status, self.summ, s, p0=True), e, what)
         if self.check:
             _summary_ok(e, self.summ, what, s)
@@ -173,10 +177,11 @@ class FpMul(_Capturable):
         self.check = check
         e, n, N, k, m, s = self.eng, self.n, self.N, self.k, self.m, self.stream
         # the [party][N] arrays are contiguous: one launch per step for ALL parties (public operands broadcast)
-        _check(e.dev_elem("beaver_open_shares", [self.ta, self.tb, self.x, self.y, self.dsh, self.esh], n * N, stream=s), e,
+        _check(e.dev_beaver_open_shares_paired(self.ta, self.tb, self.x, self.y, N, n, self.desh, s), e,
                "open shares")                         # multiplication.rs:417-426
-        self._open(self.dsh, self.dop, "open a-x")   # reconstruct_rbc: per-element recover_secret (:102-139)
-        self._open(self.esh, self.eop, "open b-y")
+        # reconstruct_rbc: per-element recover_secret of a - x and of b - y (:102-139) -- ONE interpolation call over the
+        # 2 N values of every sender row
+        self._open(self.desh, self.deop, "open a-x, b-y", values=2 * N)
         _check(e.dev_elem_parties("beaver_finalize", [self.tc, self.x, self.y, self.dop, self.eop, self.z], N, n, stream=s), e,
                "beaver_finalize")                     # finalize_mul (:57-100)
         _check(e.dev_elem_parties("truncpr_rdash", [self.rbits, self.rdash], N, n, extra=(m,), stream=s), e, "rdash")

@@ -161,3 +161,24 @@ def test_triple_encode_fused_equals_two_launches(pkg_eng, n, t, G, parties):
         assert torch.equal(y3, y1)
     else:
         assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, 0, y1.data_ptr()) == 4
+
+
+@pytest.mark.parametrize("N,parties", [(1, 1), (77, 4), (1000, 16), (5000, 3)])
+def test_beaver_open_shares_paired(pkg_eng, N, parties):
+    """hbmpc_dev_beaver_open_shares_paired: de[party][0][N] = a - x, de[party][1][N] = b - y, i.e. the two outputs of
+    hbmpc_dev_beaver_open_shares (multiplication.rs:417-426) interleaved per party; and the pair opens with ONE
+    interpolation call over 2 N values per sender"""
+    import torch
+    pkg, eng = pkg_eng
+    dev = torch.device("cuda", 0)
+    a, b, x, y = (torch.from_numpy(O.fill_random(80 + k, parties * N).view(np.int64)).to(dev) for k in range(4))
+    d1 = torch.full((parties * N, 4), -1, dtype=torch.int64, device=dev)
+    e1 = torch.full((parties * N, 4), -1, dtype=torch.int64, device=dev)
+    de = torch.full((parties, 2, N, 4), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_elem("beaver_open_shares", [a.data_ptr(), b.data_ptr(), x.data_ptr(), y.data_ptr(), d1.data_ptr(), e1.data_ptr()], parties * N) == 0
+    assert eng.dev_beaver_open_shares_paired(a.data_ptr(), b.data_ptr(), x.data_ptr(), y.data_ptr(), N, parties, de.data_ptr()) == 0
+    eng.sync()
+    assert torch.equal(de[:, 0].reshape(parties * N, 4), d1) and torch.equal(de[:, 1].reshape(parties * N, 4), e1)
+    want = O.fr_binop("sub", a[:N].cpu().numpy().view(np.uint64), x[:N].cpu().numpy().view(np.uint64))
+    assert GU.eq(de[0, 0].cpu().numpy().view(np.uint64), want)
