@@ -322,6 +322,17 @@ ShareErrorCode hbmpc_dev_beaver_open_shares(hbmpc_ctx* ctx, const U256* a, const
                                             const U256* y, size_t N, U256* d_sh_out, U256* e_sh_out, void* stream);
 ShareErrorCode hbmpc_dev_beaver_finalize(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d,
                                          const U256* e, size_t N, U256* z_out, void* stream);
+/* FPMulNode's local math between its two rounds of opens in one launch, for `parties` parties (c, x, y, r_int, z_out,
+ * r_dash_out, open_out: [party][N]; r_bits: [party][m][N]; d, e: the opened values, [N]):
+ *   z = c - d e - d y - e x                      (finalize_mul, multiplication.rs:57-100)
+ *   r' = sum_{j<m} 2^j r_bits[j]                 (truncpr.rs:277-283)
+ *   open = (z + 2^(k-1)) + (2^m r_int + r')      (truncpr.rs:275,294-297)
+ * i.e. hbmpc_dev_beaver_finalize_parties, hbmpc_dev_truncpr_rdash_parties and hbmpc_dev_truncpr_open_share back to back
+ * with the same bytes in all three outputs; at the batch sizes the protocols use every launch is several microseconds
+ * of a ~50 us multiplication. */
+ShareErrorCode hbmpc_dev_fpmul_middle(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d, const U256* e,
+                                      const U256* r_bits, const U256* r_int, size_t k, size_t m, size_t N, size_t parties,
+                                      U256* z_out, U256* r_dash_out, U256* open_out, void* stream);
 /* beaver_open_shares for `parties` parties at once (a, b, x, y: [party][N]) with a party's two results side by side:
  * de_sh_out[party][0][N] = a - x, [party][1][N] = b - y.  One robust interpolation over 2 N values per sender
  * (hbmpc_dev_batch_recover_p0 with G = 2 N: the sender rows are the parties' rows of de_sh_out) then opens d and e

@@ -169,9 +169,8 @@ class FpMul : public CapturablePipeline {
         pl_check(hbmpc_dev_beaver_open_shares_paired(ctx_, ta, tb, x, y, N, n, desh_, stream_), ctx_, "beaver_open_shares");  // multiplication.rs:417-426
         // reconstruct_rbc: per-element recover_secret of a - x and of b - y (:102-139) -- ONE call over the 2 N values of a sender row
         open(desh_, dop_, "open a-x, b-y", 2 * N);
-        pl_check(hbmpc_dev_beaver_finalize_parties(ctx_, tc, x, y, dop_, eop_, N, n, z, stream_), ctx_, "beaver_finalize");  // :57-100
-        pl_check(hbmpc_dev_truncpr_rdash_parties(ctx_, rbits, m_, N, n, rdash_, stream_), ctx_, "truncpr_rdash");  // truncpr.rs:277-283
-        pl_check(hbmpc_dev_truncpr_open_share(ctx_, z, rdash_, rint, k_, m_, n * N, osh_, stream_), ctx_, "truncpr_open_share");
+        // finalize_mul (:57-100), r' (truncpr.rs:277-283) and the share TruncPr opens (:294-297): one launch
+        pl_check(hbmpc_dev_fpmul_middle(ctx_, tc, x, y, dop_, eop_, rbits, rint, k_, m_, N, n, z, rdash_, osh_, stream_), ctx_, "fpmul_middle");
         open(osh_, cop_, "open b+r");  // truncpr.rs:215
         pl_check(hbmpc_dev_truncpr_finalize_parties(ctx_, z, rdash_, cop_, m_, N, n, out, stream_), ctx_, "truncpr_finalize");  // :216-220
     }

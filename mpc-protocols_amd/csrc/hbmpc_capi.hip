@@ -1229,6 +1229,26 @@ extern "C" ShareErrorCode hbmpc_dev_truncpr_open_share(hbmpc_ctx* ctx, const U25
     BY_IMPL(k_truncpr_open, W(a), W(r_dash), W(r_int), N, cs, WO(open_out));
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_dev_fpmul_middle(hbmpc_ctx* ctx, const U256* c, const U256* x, const U256* y, const U256* d,
+                                                 const U256* e, const U256* r_bits, const U256* r_int, size_t k, size_t m, size_t N,
+                                                 size_t parties, U256* z_out, U256* r_dash_out, U256* open_out, void* stream) {
+    REQ_FR(ctx);
+    if (ctx && k == 0) return fail(ctx, InvalidInput, "k must be >= 1 (2^(k-1))");
+    ELEM_PROLOGUE
+    CHECK_PARTIES(parties);
+    if (m > 4096) return fail(ctx, InvalidInput, "m beyond the supported range");
+    if (!c || !x || !y || !d || !e || !r_int || !z_out || !r_dash_out || !open_out || (m && !r_bits)) return fail(ctx, InvalidInput, "null buffer");
+    const uint32_t* pow2;
+    const int impl = ctx->impl;
+    ShareErrorCode rc = get_table(ctx, key("pow2", {m}, impl), [&] { return build_pow2(m, impl); }, &pow2);
+    if (rc != ShareSuccess) return rc;
+    const HFr two = HFr::from_u64(2);
+    const HFr p2m = two.pow_u64(m), p2k = two.pow_u64(k - 1);
+    const ElemConsts cs = elem_consts(impl, &p2m, &p2k);
+    BY_IMPL_P(N >= ((size_t)1 << 16) ? 1 : parties, k_fpmul_middle, W(c), W(x), W(y), W(d), W(e), W(r_bits), W(r_int), (int)m, N, cs, pow2,
+              WO(z_out), WO(r_dash_out), WO(open_out), (unsigned)parties);
+    return ShareSuccess;
+}
 static ShareErrorCode truncpr_finalize_impl(hbmpc_ctx* ctx, const U256* a, const U256* r_dash, const U256* c_open, size_t m,
                                             size_t N, size_t parties, U256* d_out, void* stream) {
     REQ_FR(ctx);

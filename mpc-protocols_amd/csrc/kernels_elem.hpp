@@ -171,6 +171,53 @@ __global__ __launch_bounds__(256) void k_truncpr_open(const uint32_t* __restrict
     acc = F::add(acc, F::load(r_dash + i * F::EW));
     F::store_loose(out + i * F::EW, acc);
 }
+// FPMulNode between its two rounds of opens, in ONE launch (at the batch sizes the protocols use every launch is ~4 us of
+// a ~50 us multiplication): finalize_mul (multiplication.rs:57-100), r' (truncpr.rs:277-283) and the share that TruncPr opens
+// (truncpr.rs:275,294-297) --
+//   z = c - d (e + [y]) - e [x];   r' = sum_j 2^j r_bits[j];   open = (z + 2^(k-1)) + (2^m r_int + r')
+// d, e public [N]; everything else [party][N] (r_bits [party][m][N]).  cs.r2 = R^2, cs.c0 = 2^m (const form), cs.c1 = 2^(k-1).
+// gridDim.y = 1: the thread serves every party; gridDim.y = parties: one party each (k_beaver_finalize).
+template <class F>
+__global__ __launch_bounds__(256) void k_fpmul_middle(const uint32_t* __restrict__ c, const uint32_t* __restrict__ x,
+                                                      const uint32_t* __restrict__ y, const uint32_t* __restrict__ d,
+                                                      const uint32_t* __restrict__ e, const uint32_t* __restrict__ r_bits,
+                                                      const uint32_t* __restrict__ r_int, int m, size_t N, ElemConsts cs,
+                                                      const uint32_t* __restrict__ pow2, uint32_t* __restrict__ z,
+                                                      uint32_t* __restrict__ r_dash, uint32_t* __restrict__ open_out,
+                                                      unsigned parties) {
+    using E = typename F::E;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const E ev = F::load(e + i * F::EW);
+    const E dm = F::mulc(F::load(d + i * F::EW), cs.r2), em = F::mulc(ev, cs.r2);
+    for (unsigned p = blockIdx.y; p < parties; p += gridDim.y) {
+        const size_t ip = (size_t)p * N + i;
+        const E dey = F::mont(F::add(ev, F::load(y + ip * F::EW)), dm);
+        const E ex = F::mont(F::load(x + ip * F::EW), em);
+        E acc = F::template sub<4>(F::load(c + ip * F::EW), dey);
+        acc = F::template sub<4>(acc, ex);
+        const E zc = F::canon_loose(acc);  // the canonical z: what k_truncpr_open would load
+        F::store_lt2r(z + ip * F::EW, zc);
+        typename F::Acc ra;
+        F::acc_zero(ra);
+        int pending = 0;
+        for (int j = 0; j < m; ++j) {
+            if (pending == F::MAX_DOT_TERMS) {
+                F::acc_fold(ra);
+                pending = 1;
+            }
+            F::acc_mac(ra, F::load(r_bits + (((size_t)p * m + j) * N + i) * F::EW), pow2 + (size_t)j * F::NL);
+            ++pending;
+        }
+        F::acc_fold(ra);
+        const E rd = F::canon_loose(F::acc_reduce(ra));
+        F::store_lt2r(r_dash + ip * F::EW, rd);
+        E o = F::add(zc, F::load_const(cs.c1));
+        o = F::add(o, F::mulc(F::load(r_int + ip * F::EW), cs.c0));
+        o = F::add(o, rd);
+        F::store_loose(open_out + ip * F::EW, o);
+    }
+}
 // truncpr.rs:215-220 + fpmul/mod.rs:381-406:  d = (a - ((c mod 2^m) - r_dash)) * (2^m)^-1;  cs.c0 = (2^m)^-1
 template <class F>
 __global__ __launch_bounds__(256) void k_truncpr_finalize(const uint32_t* __restrict__ a,

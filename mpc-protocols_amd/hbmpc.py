@@ -432,6 +432,12 @@ class Engine:
                [C.c_size_t(N), C.c_size_t(parties)] + [C.c_void_p(p) for p in ptrs[name_inputs(name):]] + [C.c_void_p(stream)]
         return getattr(self.L, self._pfx + "dev_" + name + "_parties")(*args)
 
+    def dev_fpmul_middle(self, c_d, x_d, y_d, d_d, e_d, rbits_d, rint_d, k, m, N, parties, z_d, rdash_d, open_d, stream=0):
+        """finalize_mul + r' + the share TruncPr opens, one launch (hbmpc_dev_fpmul_middle)"""
+        return self.L.hbmpc_dev_fpmul_middle(self.ctx, *(C.c_void_p(p) for p in (c_d, x_d, y_d, d_d, e_d, rbits_d, rint_d)),
+                                             C.c_size_t(k), C.c_size_t(m), C.c_size_t(N), C.c_size_t(parties),
+                                             C.c_void_p(z_d), C.c_void_p(rdash_d), C.c_void_p(open_d), C.c_void_p(stream))
+
     def dev_beaver_open_shares_paired(self, a_d, b_d, x_d, y_d, N, parties, de_d, stream=0):
         """de[party][0][N] = a - x, de[party][1][N] = b - y: one P(0) decode over 2 N values per sender opens both"""
         return self._f("dev_beaver_open_shares_paired")(self.ctx, C.c_void_p(a_d), C.c_void_p(b_d), C.c_void_p(x_d), C.c_void_p(y_d),

@@ -182,11 +182,9 @@ class FpMul(_Capturable):
         # reconstruct_rbc: per-element recover_secret of a - x and of b - y (:102-139) -- ONE interpolation call over the
         # 2 N values of every sender row
         self._open(self.desh, self.deop, "open a-x, b-y", values=2 * N)
-        _check(e.dev_elem_parties("beaver_finalize", [self.tc, self.x, self.y, self.dop, self.eop, self.z], N, n, stream=s), e,
-               "beaver_finalize")                     # finalize_mul (:57-100)
-        _check(e.dev_elem_parties("truncpr_rdash", [self.rbits, self.rdash], N, n, extra=(m,), stream=s), e, "rdash")
-        _check(e.dev_elem("truncpr_open_share", [self.z, self.rdash, self.rint, self.osh], n * N, extra=(k, m), stream=s), e,
-               "truncpr open share")                  # truncpr.rs:277-297
+        # finalize_mul (multiplication.rs:57-100), r' and the share TruncPr opens (truncpr.rs:277-297): one launch
+        _check(e.dev_fpmul_middle(self.tc, self.x, self.y, self.dop, self.eop, self.rbits, self.rint, k, m, N, n, self.z,
+                                  self.rdash, self.osh, s), e, "finalize_mul + r' + truncpr open share")
         self._open(self.osh, self.cop, "open b+r")   # truncpr.rs:215
         _check(e.dev_elem_parties("truncpr_finalize", [self.z, self.rdash, self.cop, self.out], N, n, extra=(m,), stream=s), e,
                "truncpr finalize")                    # truncpr.rs:216-220

@@ -182,3 +182,24 @@ def test_beaver_open_shares_paired(pkg_eng, N, parties):
     assert torch.equal(de[:, 0].reshape(parties * N, 4), d1) and torch.equal(de[:, 1].reshape(parties * N, 4), e1)
     want = O.fr_binop("sub", a[:N].cpu().numpy().view(np.uint64), x[:N].cpu().numpy().view(np.uint64))
     assert GU.eq(de[0, 0].cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("N,parties,k,m", [(1, 1, 16, 4), (77, 4, 16, 4), (1000, 16, 32, 16), (70000, 2, 16, 0), (300, 3, 40, 33)])
+def test_fpmul_middle_equals_the_three_calls(pkg_eng, N, parties, k, m):
+    """hbmpc_dev_fpmul_middle = beaver_finalize_parties + truncpr_rdash_parties + truncpr_open_share, byte for byte in all
+    three outputs (both the in-thread party loop of large N and the party-per-block form of small N)"""
+    import torch
+    pkg, eng = pkg_eng
+    dev = torch.device("cuda", 0)
+    c, x, y, rint = (torch.from_numpy(O.fill_random(90 + q, parties * N).view(np.int64)).to(dev) for q in range(4))
+    d, e = (torch.from_numpy(O.fill_random(95 + q, N).view(np.int64)).to(dev) for q in range(2))
+    bits = torch.from_numpy(O.fill_random(99, parties * max(m, 1) * N).view(np.int64)).to(dev)   # any field elements will do
+    z1, rd1, o1, z2, rd2, o2 = (torch.full((parties * N, 4), -1, dtype=torch.int64, device=dev) for _ in range(6))
+    torch.cuda.synchronize()
+    P = lambda t_: t_.data_ptr()   # noqa: E731
+    assert eng.dev_elem_parties("beaver_finalize", [P(c), P(x), P(y), P(d), P(e), P(z1)], N, parties) == 0
+    assert eng.dev_elem_parties("truncpr_rdash", [P(bits), P(rd1)], N, parties, extra=(m,)) == 0
+    assert eng.dev_elem("truncpr_open_share", [P(z1), P(rd1), P(rint), P(o1)], parties * N, extra=(k, m)) == 0
+    assert eng.dev_fpmul_middle(P(c), P(x), P(y), P(d), P(e), P(bits), P(rint), k, m, N, parties, P(z2), P(rd2), P(o2)) == 0
+    eng.sync()
+    assert torch.equal(z1, z2) and torch.equal(rd1, rd2) and torch.equal(o1, o2)
