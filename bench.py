@@ -716,13 +716,31 @@ def pipeline_measurements(eng, torch, dev, stream, ev_time):
     _share_on_device(eng, torch, dev, stream, r, n, 2 * t, tg.r2t)
     tg.run(check=True)  # one checked run: every decode reports zero failures
     ms = ev_time(lambda: tg.run(check=False), reps=5, warm=1)
-    tg.capture()  # the same ~150 launches recorded once into a HIP graph
+    tg.capture()  # the same launches recorded once into a HIP graph
     ms_graph = ev_time(tg.replay, reps=5, warm=1)
     res["cfg4_triple_gen_16_parties"] = {"triples_per_s": N / min(ms, ms_graph) * 1e3, "ms": ms, "ms_hip_graph": ms_graph,
                                          "triples": N,
                                          "note": "all 16 simulated parties on one GPU: local mul, encode, 16 P(0) decodes, reveal decode, finalize"}
     tg.close()
     del a, b, r
+    # the same at a protocol-sized batch: 1100 and 11000 triples per party (100 / 1000 chunks of 2t+1)
+    for groups in (100, 1000):
+        Ns = groups * (2 * t + 1)
+        tg = pl.TripleGen(eng, n, t, Ns, stream)
+        a, b, r = (_rand_fr(torch, dev, Ns) for _ in range(3))
+        _share_on_device(eng, torch, dev, stream, a, n, t, tg.a)
+        _share_on_device(eng, torch, dev, stream, b, n, t, tg.b)
+        _share_on_device(eng, torch, dev, stream, r, n, t, tg.rt)
+        _share_on_device(eng, torch, dev, stream, r, n, 2 * t, tg.r2t)
+        tg.run(check=True)
+        tg.run(check=False)
+        ms_eager = ev_time(lambda: tg.run(check=False), reps=20, warm=2)
+        tg.capture()
+        ms_graph = ev_time(tg.replay, reps=20, warm=2)
+        res[f"cfg4_triple_gen_{Ns}_triples"] = {"triples": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
+                                                "triples_per_s_hip_graph": Ns / ms_graph * 1e3}
+        tg.close()
+        del a, b, r
     # config 5: fpmul, n=16, t=5, 2^18 elements, (k, f) = (16, 4)
     N, k, m = 1 << 18, 16, 4
     fp = setup_fpmul(eng, torch, dev, stream, n, t, N, k, m)
