@@ -307,9 +307,10 @@ ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256*
 /* TripleGenNode::init_batch for `parties` simulated parties in one launch: [ab - r]_2t = a_i b_i - r2t_i per element
  * (triple_gen/triple_generation.rs:333-340) followed by the BatchRecon encode of the chunks of d + 1 = 2t + 1 values
  * (batch_recon/batch_recon.rs:157-165): a, b, r2t are [parties][G (d+1)], y_out is [parties][n][G] exactly as
- * hbmpc_dev_vandermonde_apply_parties writes it.  Where a fused kernel exists (bls12-381 Fr, domains up to 16 points,
- * d + 1 in {3, 5, 7, 9, 11}) the local products never touch HBM; other shapes run the two launches through tmp_dev
- * (parties G (d+1) elements; may be NULL only when the fused kernel applies -- InvalidInput otherwise).  Results are
+ * hbmpc_dev_vandermonde_apply_parties writes it.  Where a fused kernel exists (either field, domains up to 16 points,
+ * d + 1 in {3, 5, 7, 9, 11}) the local products never touch HBM; other shapes -- and, when tmp_dev is given, batches of
+ * at most 2 048 chunks over all parties, where two short launches beat the one long one -- run the two launches through
+ * tmp_dev (parties G (d+1) elements; may be NULL only when the fused kernel applies -- InvalidInput otherwise).  Results are
  * those of hbmpc_dev_triple_local followed by hbmpc_dev_vandermonde_apply_parties, bit for bit. */
 ShareErrorCode hbmpc_dev_triple_encode_parties(hbmpc_ctx* ctx, const U256* a_dev, const U256* b_dev, const U256* r2t_dev,
                                                size_t G, size_t n, size_t d, size_t parties, U256* tmp_dev, U256* y_out_dev,
