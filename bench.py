@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the Shamir share-arithmetic hot path on MI355X.
 
-Contract: python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run,
-one rank per GPU).  A "step" is one pass of RobustShare::compute_shares over one resident batch:
+Contract: python bench.py --gpus N --steps K --warmup W   (N > 1: one rank per GPU under torch.distributed.run; started
+WITHOUT a launcher -- no WORLD_SIZE in the environment -- bench.py starts that launcher itself as a child process before
+anything touches the GPU and relays rank 0's JSON line; --single-process drives the N devices from ONE process instead, a
+context and a host thread per device, with the library's own gather: what a Rust node that owns all its devices does).  A "step" is one pass of RobustShare::compute_shares over one resident batch:
 BASELINE.json configs[1] -- n=16, t=5, 2^20 secrets, 256-bit Fr -- per GPU (weak scaling: batches are
 independent, there is no data-path collective).  Rank 0 prints ONE JSON line.
 
@@ -161,6 +163,172 @@ def traffic_record(key):
         return None
 
 
+def launch_command(n, argv, port):
+    """the child command of an N-rank run: exactly what the driver's own launcher line is"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--print-launch"]
+
+
+def launch_ranks(n, argv, print_only=False):
+    """N > 1 without a launcher: start `python -m torch.distributed.run ... bench.py <same arguments>` as a child, pass its
+    stderr through, print the JSON line of rank 0 (the last stdout line that parses as the bench record) and return the
+    child's exit code.  Never an exec: a process that may have initialised the GPU must not be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = launch_command(n, argv, port)
+    if print_only:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL / IPC on this stack need the dmabuf path
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    record = None
+    for line in proc.stdout:
+        try:
+            obj = json.loads(line)
+            if isinstance(obj, dict) and "metric" in obj:
+                record = line.rstrip("\n")
+                continue
+        except ValueError:
+            pass
+        sys.stderr.write(line)  # anything else the ranks printed
+    rc = proc.wait()
+    if record is not None:
+        print(record)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a bench record\n")
+        rc = 1
+    return rc
+
+
+def bench_single_process(args, torch):
+    """--single-process --gpus N: one process, one Engine (context) + one host thread per device.  Every device runs the
+    two halves of the metric on its own 2^20-element shard (weak scaling, no data-path collective: the same steps as the
+    process-per-GPU mode), the threads meet at a barrier before and after the K timed steps and the slowest one sets the
+    time; then the shares of all devices are gathered party-major onto device 0 by hbmpc_dev_gather_party_major (one strided
+    copy per shard over xGMI) -- the final gather a host that owns all its devices issues, timed separately."""
+    import threading
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    N = args.gpus
+    n, t, d = 16, 5, 5
+    n3, t3, d3 = 31, 10, 10
+    B = 1 << args.log2_batch
+    devno = [0 if args.same_device else i for i in range(N)]  # --same-device: rehearsal of the control flow on one GPU
+    engines = [pkg.Engine(devno[i], impl=args.impl) for i in range(N)]
+    for e in engines:
+        e.set_matrix_cores(args.recon_kernels == "mfma")
+    peer = [engines[0].peer_access(e) for e in engines]
+    bar = threading.Barrier(N)
+    res = [None] * N
+    keep = [None] * N
+    errs = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(devno[i])
+            dev = torch.device("cuda", devno[i])
+            eng = engines[i]
+            ts = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(ts)
+            stream = ts.cuda_stream
+            torch.manual_seed(0xC0FFEE01 + i)
+            coeffs = _rand_fr(torch, dev, B, d + 1)
+            shares = torch.empty((n, B, 4), dtype=torch.int64, device=dev)
+
+            def step():
+                rc = eng.dev_compute_shares(coeffs.data_ptr(), B, n, d, shares.data_ptr(), stream)
+                if rc != 0:
+                    raise RuntimeError(f"hbmpc_dev_compute_shares -> {rc}: {eng.last_error()}")
+
+            sync = lambda: torch.cuda.synchronize(dev)
+            ev = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), lambda e: e.record(ts))
+            step()
+            sync()
+            tm = timed_steps(step, args.steps, args.warmup, sync, bar.wait, lambda x: x, prewarm_s=args.prewarm_seconds, events=ev())
+            torch.manual_seed(0xC0FFEE02 + i)
+            x = _rand_fr(torch, dev, B, d3 + 1)
+            y = torch.empty((n3, B, 4), dtype=torch.int64, device=dev)
+            co = torch.empty((B, d3 + 1, 4), dtype=torch.int64, device=dev)
+            st = torch.empty((B,), dtype=torch.uint8, device=dev)
+            summ = torch.zeros((4,), dtype=torch.int32, device=dev)
+            ids = list(range(n3))
+            assert eng.dev_vandermonde_apply(x.data_ptr(), B, n3, d3, y.data_ptr(), stream) == 0, eng.last_error()
+
+            def rstep():
+                rc = eng.dev_batch_recover(ids, y.data_ptr(), B, n3, d3, t3, co.data_ptr(), 0, st.data_ptr(), summ.data_ptr(), stream)
+                if rc != 0:
+                    raise RuntimeError(f"hbmpc_dev_batch_recover -> {rc}: {eng.last_error()}")
+
+            rstep()
+            sync()
+            assert bool((co == x).all()) and int(st.max()) == 0, "decode(encode(x)) != x"
+            rtm = timed_steps(rstep, args.steps, args.warmup, sync, bar.wait, lambda x: x, prewarm_s=args.prewarm_seconds, events=ev())
+            res[i] = (tm, rtm)
+            keep[i] = (shares, ts)
+        except BaseException as e:  # a thread that dies must not leave the others at the barrier
+            errs.append((i, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(N)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if errs:
+        raise SystemExit(f"--single-process: {errs}")
+    secs = max(r[0]["secs"] for r in res)
+    rsecs = max(r[1]["secs"] for r in res)
+    kernel_ms = max(r[0]["kernel_ms"] for r in res)
+    rkernel_ms = max(r[1]["kernel_ms"] for r in res)
+    algo = (d + 1 + n) * 32 * B
+    r_algo = (d3 + t3 + 1 + d3 + 1) * 32 * B
+    out = {
+        "metric": "shares/sec (compute_shares) + recons/sec (batch_recon), 256-bit Fr, 1/2/4/8 GPU",
+        "value": n * B * N * args.steps / secs, "unit": "shares/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": secs / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"compute_shares n={n} t={t} batch=2^{args.log2_batch} secrets per GPU (BASELINE configs[1])",
+                   "field": "bls12-381 Fr", "parallelism": f"batch-sharded x{N}, ONE process with a context and a host thread per device, "
+                                                             "no data-path collective", "field_impl": args.impl},
+        "roofline": {"bound": "hbm", "achieved": algo / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_eval_fft1<U29,4,6>",
+                     "kernel_ms": kernel_ms, "algorithmic_bytes": algo, "note": "slowest device; per-device kernel_ms in per_device"},
+        "recon": {"value": B * N * args.steps / rsecs, "unit": "recons/s", "ms_per_step": rsecs / args.steps * 1e3,
+                  "roofline": {"bound": "hbm", "achieved": r_algo / (rkernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": r_algo / (rkernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": rkernel_ms}},
+        "per_device": [{"device": i, "kernel_ms": res[i][0]["kernel_ms"], "recon_kernel_ms": res[i][1]["kernel_ms"]} for i in range(N)],
+    }
+    out["recons_per_s"] = out["recon"]["value"]
+    if not args.no_final_gather:
+        torch.cuda.set_device(0)
+        full = torch.empty((n, B * N, 4), dtype=torch.int64, device=torch.device("cuda", 0))
+        ts0 = keep[0][1]
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ptrs = [keep[i][0].data_ptr() for i in range(N)]
+        for rep in range(2):  # the first call enables peer access and maps the peers' memory
+            g0.record(ts0)
+            rc = pkg.Engine.gather_party_major(engines, 0, ptrs, [B] * N, [B] * N, n, full.data_ptr(), B * N, sync_sources=True,
+                                               stream=ts0.cuda_stream)
+            assert rc == 0, engines[0].last_error()
+            g1.record(ts0)
+            torch.cuda.synchronize()
+        ms = g0.elapsed_time(g1)
+        for i in range(N):
+            assert torch.equal(full[:, i * B:(i + 1) * B].cpu(), keep[i][0].cpu()), f"gathered shard {i} differs"
+        out["final_gather"] = {"ms": ms, "bytes_total": n * B * N * 32, "bytes_from_peers": n * B * (N - 1) * 32,
+                               "GBps_from_peers": n * B * (N - 1) * 32 / ms / 1e6,
+                               "copies": "one hipMemcpy2DAsync per shard on device 0's stream (hbmpc_dev_gather_party_major)",
+                               "peer_access_direct": peer}
+    if args.same_device:
+        out["rehearsal"] = "every context on GPU 0: a check of the one-process control flow, not a measurement"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,19 +350,35 @@ def main():
                          "the N > 1 control flow where RCCL cannot run, e.g. several ranks on one GPU with --same-device)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (with --dist-backend gloo); the numbers then mean nothing")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N > 1 from ONE process: an Engine (context) and a host thread per device, each on its shard, then "
+                         "hbmpc_dev_gather_party_major to device 0 (no torch.distributed, no RCCL bootstrap)")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="N > 1 without a launcher: print the child command line as JSON and exit (used by the CPU tests)")
     ap.add_argument("--impl", default="u29", choices=["u29", "sat32"])
     ap.add_argument("--recon-kernels", default="mfma", choices=["mfma", "lane"],
                     help="batch_recover on the matrix cores (default) or with the lane-per-chunk kernels (A/B)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and not args.single_process and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: become the launcher's parent.  Nothing in this process has touched the GPU (torch is
+        # not even imported yet), the ranks are CHILD processes, and this process only relays and exits with their code.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.print_launch))
+
     import torch
     import torch.distributed as dist
+
+    if args.single_process and args.gpus > 1:
+        if not torch.cuda.is_available() or (torch.cuda.device_count() < args.gpus and not args.same_device):
+            raise SystemExit(f"--single-process --gpus {args.gpus}: {torch.cuda.device_count() if torch.cuda.is_available() else 0} devices visible")
+        print(json.dumps(bench_single_process(args, torch)))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path")
     if args.same_device:

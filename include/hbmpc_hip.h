@@ -136,6 +136,10 @@ ShareErrorCode hbmpc_dev_gather_party_major(hbmpc_ctx* const* ctxs, size_t n_sha
                                             const void* const* shards_dev, const size_t* counts, const size_t* strides,
                                             size_t n_rows, void* out_dev, size_t out_stride, int sync_sources,
                                             void* stream);
+/* *direct_out = 1 when root's device reads source's memory directly (same device, or peer access over xGMI, which this
+ * call enables): the gather is then one strided copy per shard; 0 when the runtime has to stage the rows through the
+ * host.  (The reference has no counterpart: its parties exchange bytes through the Network trait.) */
+ShareErrorCode hbmpc_dev_peer_access(hbmpc_ctx* root, hbmpc_ctx* source, int* direct_out);
 
 /* ---- HIP graphs (for hosts without their own HIP binding) ----------------------------------------
  * The reference's regime is many small protocol steps (a few hundred elements per message); a device-resident

@@ -402,21 +402,51 @@ extern "C" ShareErrorCode hbmpc_dev_gather_party_major(hbmpc_ctx* const* ctxs, s
     size_t col = 0;
     for (size_t r = 0; r < n_shards; ++r) {
         const int src_dev = ctxs[r]->device;
-        if (src_dev != rc_ctx->device) {
+        bool direct = src_dev == rc_ctx->device;
+        if (!direct) {
             int can = 0;
             HIP_TRY(rc_ctx, hipDeviceCanAccessPeer(&can, rc_ctx->device, src_dev));
             if (can) {
                 const hipError_t e = hipDeviceEnablePeerAccess(src_dev, 0);  // idempotent across calls
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(rc_ctx, e);
                 (void)hipGetLastError();
+                direct = true;
             }
         }
-        for (size_t j = 0; j < n_rows && counts[r]; ++j) {
-            char* dst = (char*)out_dev + (j * out_stride + col) * eb;
-            const char* src = (const char*)shards_dev[r] + j * strides[r] * eb;
-            HIP_TRY(rc_ctx, hipMemcpyPeerAsync(dst, rc_ctx->device, src, src_dev, counts[r] * eb, s));
+        if (counts[r] && n_rows) {
+            char* dst = (char*)out_dev + col * eb;
+            const char* src = (const char*)shards_dev[r];
+            if (direct) {
+                // ONE strided copy per shard: n_rows row segments of counts[r] elements (the destination reads the source
+                // over xGMI when the devices differ)
+                HIP_TRY(rc_ctx, hipMemcpy2DAsync(dst, out_stride * eb, src, strides[r] * eb, counts[r] * eb, n_rows, hipMemcpyDeviceToDevice, s));
+            } else {
+                // no peer access between the two devices: the runtime stages every row through the host
+                for (size_t j = 0; j < n_rows; ++j)
+                    HIP_TRY(rc_ctx, hipMemcpyPeerAsync(dst + j * out_stride * eb, rc_ctx->device, src + j * strides[r] * eb, src_dev, counts[r] * eb, s));
+            }
         }
         col += counts[r];
+    }
+    return ShareSuccess;
+}
+// 1: the root's device reads the source's memory directly (same device, or peer access over xGMI, enabled here);
+// 0: hbmpc_dev_gather_party_major falls back to copies the runtime stages through the host
+extern "C" ShareErrorCode hbmpc_dev_peer_access(hbmpc_ctx* root, hbmpc_ctx* source, int* direct_out) {
+    if (!root || !source || !direct_out) return InvalidInput;
+    *direct_out = 0;
+    if (root->device == source->device) {
+        *direct_out = 1;
+        return ShareSuccess;
+    }
+    int can = 0;
+    HIP_TRY(root, hipSetDevice(root->device));
+    HIP_TRY(root, hipDeviceCanAccessPeer(&can, root->device, source->device));
+    if (can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(source->device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(root, e);
+        (void)hipGetLastError();
+        *direct_out = 1;
     }
     return ShareSuccess;
 }

@@ -125,6 +125,14 @@ class Engine:
                                                             C.c_void_p(out_d), C.c_size_t(out_stride), C.c_int(1 if sync_sources else 0),
                                                             C.c_void_p(stream))
 
+    def peer_access(self, source: "Engine") -> bool:
+        """True when this engine's device reads `source`'s memory directly (same device or peer access over xGMI)"""
+        out = C.c_int(0)
+        rc = self.L.hbmpc_dev_peer_access(self.ctx, source.ctx, C.byref(out))
+        if rc != 0:
+            raise HbmpcError(rc, self.last_error())
+        return bool(out.value)
+
     def set_matrix_cores(self, on: bool, min_chunks: int = 0):
         """large Fr decodes on the matrix cores (int8 MFMA); min_chunks = 0 keeps the current threshold"""
         # on: False / True, or 2 = matrix cores without the workgroup-per-tile kernel of small batches (A/B)

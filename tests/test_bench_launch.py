@@ -1,0 +1,47 @@
+"""bench.py --gpus N started WITHOUT a launcher ("Next round" item 2): before anything touches the GPU it
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, relays rank 0's JSON line and
+exits with the child's code.  No GPU here: the command line is asserted, and a real spawn is followed as far as the
+ranks' own "no GPU" exit."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_child_command_line():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg4", "--print-launch"],
+                         capture_output=True, text=True, env=_env(), timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout)["launch"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 0 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(BENCH)
+    # the ranks get exactly the arguments this process got (minus the test switch)
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "cfg4"]
+
+
+def test_one_gpu_needs_no_launcher():
+    # N = 1 (the default) must not spawn anything: without a GPU it ends in bench.py's own message
+    out = subprocess.run([sys.executable, BENCH, "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=_env(), timeout=300)
+    assert out.returncode != 0 and "needs an MI355X" in out.stderr and "torch.distributed" not in out.stderr
+
+
+def test_spawns_the_ranks_and_returns_their_exit_code():
+    # a real spawn: both ranks start, find no GPU and exit non-zero; the parent relays their stderr and their exit code
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                         env=_env(), timeout=600)
+    assert out.returncode != 0
+    assert out.stderr.count("needs an MI355X") >= 2, out.stderr[-2000:]
+    assert out.stdout.strip() == ""  # no bench record

@@ -186,6 +186,7 @@ def test_gather_party_major_two_contexts():
         e0.sync()
         got = out.cpu().numpy().view(np.uint64)
         assert np.array_equal(got[:, :B], want) and (got[:, B:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        assert e0.peer_access(e1) is True  # same device: direct (on a multi-GPU node: peer access over xGMI, enabled by the call)
         # argument checks: stride below count, field mismatch
         assert pkg.Engine.gather_party_major([e0, e1], 0, [s0.data_ptr(), s1.data_ptr()], [lo, B - lo], [lo - 1, B - lo], n,
                                              out.data_ptr(), B + 5) == 4
