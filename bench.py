@@ -155,6 +155,59 @@ def cpu_baseline_threads(n, d, sample, min_seconds=2.0):
             "seconds": round(dt, 2)}
 
 
+def cpu_baseline_pipeline(kind, n, t, min_seconds=5.0, k=16, f=4):
+    """configs 4 / 5 on one host thread: ONE party's step of the pipeline in the oracle's element-wise / per-chunk
+    restatement (the reference runs a party's arithmetic inline in one task), on a bounded sample repeated until
+    >= min_seconds.  The GPU line covers all n simulated parties per step: `value` here is one party's rate."""
+    from oracle import cref
+    ids = list(range(n))
+    if kind == "cfg4":
+        m, d = 2 * t + 1, 2 * t
+        G = 1 << 11
+        N = G * m
+        a, b, r2t, rt = (cref.fill_random(0xC0FFEE03 + i, N) for i in range(4))
+        reps, dt, t0 = 0, 0.0, time.perf_counter()
+        while reps < 1024 and dt < min_seconds:
+            rc, x = cref.triple_local(a, b, r2t)                              # triple_generation.rs:333-340
+            rc1, y = cref.vandermonde_apply(x.reshape(G, m, 4), n, d)         # batch_recon.rs:157-165
+            rc2, z, st = cref.batch_recover_p0(ids, y, n, d, t)               # EvalBatch arm :371-389 (G chunks of this recipient)
+            rc3, co, _, st2 = cref.batch_recover(ids, y, n, d, t)             # RevealBatch arm :457-467
+            rc4, c = cref.triple_finalize(rt, co.reshape(N, 4))               # triple_generation.rs:196-208
+            assert rc == rc1 == rc2 == rc3 == rc4 == 0 and not st.any() and not st2.any()
+            reps += 1
+            dt = time.perf_counter() - t0
+        assert np.array_equal(co.reshape(N, 4), x)
+        return {"value": N * reps / dt, "unit": "triples/s", "cores": 1, "kind": "port", "seconds": round(dt, 2),
+                "sample": f"one party's triple_gen step (local product, encode, the two BatchRecon decodes, finalize) over {N} triples, "
+                          f"{reps} passes, single thread; the GPU line runs this for all {n} parties per step",
+                "value_all_parties": N * reps / dt / n}
+    N = 1 << 13
+    x, y, ta, tb, tc, rint = (cref.fill_random(0xC0FFEE05 + i, N) for i in range(6))
+    rbits = cref.fill_random(0xC0FFEE0B, f * N).reshape(f, N, 4)
+    # what a party receives for an open: 2t+1 senders' shares of valid degree-t sharings
+    sec = cref.fill_random(0xC0FFEE0C, 2 * N * (t + 1)).reshape(2 * N, t + 1, 4)
+    rc, opn = cref.compute_shares(sec, n, t)
+    assert rc == 0
+    opn = np.ascontiguousarray(opn[: 2 * t + 1])
+    oids = list(range(2 * t + 1))
+    reps, dt, t0 = 0, 0.0, time.perf_counter()
+    while reps < 64 and dt < min_seconds:
+        rc, dsh, esh = cref.beaver_open_shares(ta, tb, x, y)                  # multiplication.rs:417-426
+        rc1, de, st = cref.batch_recover_p0(oids, opn, n, t, t)               # reconstruct_rbc :102-139 (a - x and b - y: 2 N opens)
+        rc2, z = cref.beaver_finalize(tc, x, y, de[:N], de[N:])               # finalize_mul :57-100
+        rc3, rd = cref.truncpr_rdash(rbits, f)                                # truncpr.rs:277-297
+        rc4, osh = cref.truncpr_open_share(z, rd, rint, k, f)
+        rc5, cop, st2 = cref.batch_recover_p0(oids, opn[:, :N], n, t, t)      # truncpr.rs:215
+        rc6, out = cref.truncpr_finalize(z, rd, cop, f)                       # :216-220
+        assert rc == rc1 == rc2 == rc3 == rc4 == rc5 == rc6 == 0 and not st.any() and not st2.any()
+        reps += 1
+        dt = time.perf_counter() - t0
+    return {"value": N * reps / dt, "unit": "fpmuls/s", "cores": 1, "kind": "port", "seconds": round(dt, 2),
+            "sample": f"one party's fpmul step (Beaver open shares, 2 N opens from 2t+1 senders, finalize_mul, r', TruncPr open share, "
+                      f"N opens, TruncPr finalize; (k, f) = ({k}, {f})) over {N} elements, {reps} passes, single thread; the GPU line "
+                      f"runs this for all {n} parties per step", "value_all_parties": N * reps / dt / n}
+
+
 def traffic_record(key):
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -609,6 +662,45 @@ def bench_pipeline(ctx):
         "config": {"workload": what + f" (BASELINE configs[{3 if args.workload == 'cfg4' else 4}])", "field": "bls12-381 Fr",
                    "parallelism": f"batch-sharded x{world}, all {n} simulated parties of a shard on one GPU, no data-path collective"},
     }
+    # the dominant kernel of the step against the HBM roofline: its algorithmic bytes / its own launch duration, measured
+    # live with HIP events around K launches of that call alone (same buffers, same stream)
+    e0, e1, rec = ctx["events"]()
+    if args.workload == "cfg4":
+        d2 = 2 * t
+        G = N // m
+        dom = lambda: eng.dev_triple_encode_parties(tg.a, tg.b, tg.r2t, G, n, d2, n, tg.c, tg.Y, stream)
+        dom_bytes = n * (3 * N + n * G) * 32          # per party: a, b, r2t read, Y[party][n][G] written
+        dom_name = "k_eval_fft1_triple<U29,4,11>"
+        step_bytes = dom_bytes + (n * n * G + n * G) * 32 + (n * G + N) * 32 + n * N * 64 + N * 32
+        tkey = f"triple_encode_parties_n{n}_t{t}_N{N}"
+        limiter = ("vector issue, not HBM: 11.9 k vector instructions per chunk of 11 triples (22 products a*b - r, the pruned FFT, "
+                   "canonicalisations), profiles/r02_pmc_cfg4.txt")
+    else:
+        dom = lambda: eng.dev_fpmul_middle(fp.tc, fp.x, fp.y, fp.dop, fp.eop, fp.rbits, fp.rint, k, f, N, n, fp.z, fp.rdash, fp.osh, stream)
+        dom_bytes = n * N * 32 * (7 + f) + 2 * N * 32  # c, x, y, r_int, f bit shares read, z, r', open share written per party; d, e once
+        dom_name = "k_fpmul_middle<U29>"
+        step_bytes = dom_bytes + n * N * 32 * 6 + (2 * t + 1) * 3 * N * 32 + 3 * N * 32 + n * N * 32 * 3 + N * 32
+        tkey = f"fpmul_middle_n{n}_t{t}_N{N}_f{f}"
+        limiter = "HBM (element-wise, 5 - 6 TB/s: profiles/r02_cfg5_kernel_stats.csv)"
+    for _ in range(3):
+        dom()
+    torch.cuda.synchronize()
+    rec(e0)
+    for _ in range(args.steps):
+        dom()
+    rec(e1)
+    torch.cuda.synchronize()
+    dom_ms = e0.elapsed_time(e1) / args.steps
+    ach = dom_bytes / (dom_ms * 1e-3) / 1e9
+    out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                       "kernel": dom_name, "kernel_ms": dom_ms, "algorithmic_bytes": dom_bytes, "limiter": limiter,
+                       "kernel_ms_source": "HIP events around K launches of this call alone, after the timed region",
+                       "step_algorithmic_bytes": step_bytes,
+                       "step_GBps": step_bytes / (tm["kernel_ms"] * 1e-3) / 1e9, "step_frac": step_bytes / (tm["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    trec = traffic_record(tkey)
+    if trec:
+        out["roofline"]["traffic"] = trec["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_source"] = trec["source"]
     if world > 1 and not args.no_final_gather:
         from mpc_protocols_amd import sharding
         # this rank's result shares as a torch view of the pipeline's device buffer: [n][N][4]
@@ -628,6 +720,8 @@ def bench_pipeline(ctx):
                                "collective": "all_gather of the [n][N_rank] result shares (RCCL)"}
         del full, mine
     pipe.close()
+    if rank == 0 and world == 1:
+        out["cpu_baseline"] = cpu_baseline_pipeline(args.workload, n, t)
     return out
 
 
