@@ -4,7 +4,8 @@
  * This is the drop-in boundary for ONE path of Stoffel-Labs/mpc-protocols: the field arithmetic
  * behind RobustShare<F> / SecretSharingScheme<F> (F = ark_bls12_381::Fr) that the async protocol
  * code calls inline.  Each entry point names the reference interface it replaces (paths relative
- * to the reference's mpc/src/).  The Rust shim that binds these symbols is in INTEGRATION.md.
+ * to the reference's mpc/src/).  The Rust side of the boundary is delivered as files: rust/hbmpc_sys.rs (generated from
+ * this header by tools/gen_rust_sys.py) and rust/gpu_shares.rs (the adaptor); INTEGRATION.md shows where they plug in.
  *
  * Conventions (they follow the reference's own exported C ABI, ffi/c_bindings/mod.rs:17-35 and
  * ffi/c_bindings/share/mod.rs:18-37, so both ABIs look alike):
@@ -109,7 +110,7 @@ const char* hbmpc_version(void);
 /* ---- device memory / stream helpers (for hosts without their own HIP binding) ------------ */
 /* Device buffers passed to hbmpc_dev_* should come from hbmpc_dev_alloc / hipMalloc (what torch's caching
  * allocator uses).  Stream-ordered pool memory (hipMallocAsync) is not recommended for buffers that one
- * kernel writes and the next reads: see DESIGN.md section 4, "Scratch memory". */
+ * kernel writes and the next reads: see DESIGN.md section 4, "Memory the library hands between kernels". */
 ShareErrorCode hbmpc_dev_alloc(hbmpc_ctx* ctx, size_t bytes, void** dptr_out);
 ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr);
 ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
@@ -312,8 +313,9 @@ ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256*
  * (triple_gen/triple_generation.rs:333-340) followed by the BatchRecon encode of the chunks of d + 1 = 2t + 1 values
  * (batch_recon/batch_recon.rs:157-165): a, b, r2t are [parties][G (d+1)], y_out is [parties][n][G] exactly as
  * hbmpc_dev_vandermonde_apply_parties writes it.  Where a fused kernel exists (either field, domains up to 16 points,
- * d + 1 in {3, 5, 7, 9, 11}) the local products never touch HBM; other shapes -- and, when tmp_dev is given, batches of
- * at most 2 048 chunks over all parties, where two short launches beat the one long one -- run the two launches through
+ * d + 1 in {3, 5, 7, 9, 11}) the local products never touch HBM; other shapes -- and, over Fr when tmp_dev is given,
+ * batches of at most 2 048 chunks over all parties, where two short launches beat the one long one (the small field's
+ * fused kernel is light at every size and always runs when it covers the shape) -- run the two launches through
  * tmp_dev (parties G (d+1) elements; may be NULL only when the fused kernel applies -- InvalidInput otherwise).  Results are
  * those of hbmpc_dev_triple_local followed by hbmpc_dev_vandermonde_apply_parties, bit for bit. */
 ShareErrorCode hbmpc_dev_triple_encode_parties(hbmpc_ctx* ctx, const U256* a_dev, const U256* b_dev, const U256* r2t_dev,
@@ -564,8 +566,10 @@ ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups);
 ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
 /* Secret hygiene.  The host-pointer calls stage their arguments through per-context pools (device buffers, pinned host
  * blocks) that are recycled between calls, so copies of polynomial coefficients (secrets) and shares stay there until
- * a later call overwrites them.  hbmpc_scrub_staging zeroes everything the pools hold (it drains the context's stream
- * first); hbmpc_destroy does it before freeing.  Buffers the CALLER allocated (hbmpc_dev_alloc, its own host arrays) are
+ * a later call overwrites them.  hbmpc_scrub_staging zeroes everything the pools hold at that moment (it drains the
+ * context's stream first; a block checked out by a host-pointer call running on another thread, and the per-stream
+ * kernel scratch, which only ever holds flagged-chunk indices and counters, are not in the pools); hbmpc_destroy does it
+ * before freeing.  Buffers the CALLER allocated (hbmpc_dev_alloc, its own host arrays) are
  * the caller's to clear. */
 ShareErrorCode hbmpc_scrub_staging(hbmpc_ctx* ctx);
 /* The device-table cache of a context (twiddles, Vandermonde rows, one Lagrange/verify table and one OEC/Gao table

@@ -25,6 +25,7 @@
 
 using namespace hbmpc;
 
+constexpr size_t STAGE_PIN_BLOCK = (size_t)2048 << 10;  // pinned host block of the small-call staging path (Stage, hbmpc_scrub_staging)
 struct hbmpc_ctx {
     int device = 0;
     int impl = IMPL_U29;
@@ -254,13 +255,15 @@ extern "C" ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_c
 // Staging memory of the host-pointer API holds copies of what callers passed in (polynomial coefficients, i.e. secrets,
 // shares) until a later call overwrites it: zero what the pools hold.
 extern "C" ShareErrorCode hbmpc_scrub_staging(hbmpc_ctx* ctx) {
+    // (blocks checked out by a host-pointer call running on another thread, and the per-stream scratch, are not in the
+    // pools and are not touched)
     if (!ctx) return InvalidInput;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::lock_guard<std::mutex> lk(ctx->mu);
     for (auto& b : ctx->stage_free) HIP_TRY(ctx, hipMemsetAsync(b.first, 0, b.second, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (void* q : ctx->pin_free) memset(q, 0, (size_t)2048 << 10);  // Stage::BLOCK
+    for (void* q : ctx->pin_free) memset(q, 0, STAGE_PIN_BLOCK);
     return ShareSuccess;
 }
 extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
@@ -765,7 +768,7 @@ struct DevBuf {
 // (tools/time_small_calls.py).  Only plain loads/stores touch the mapped block (the kernels' atomics -- flag lists,
 // counters -- live in device scratch; the host path derives its summary from the status bytes instead).
 struct Stage {
-    static constexpr size_t BLOCK = 2048 << 10;
+    static constexpr size_t BLOCK = STAGE_PIN_BLOCK;
     hbmpc_ctx* ctx;
     bool mapped = false, finished = false;
     char* hblk = nullptr;  // host view of the block

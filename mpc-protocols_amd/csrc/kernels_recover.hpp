@@ -115,9 +115,11 @@ HB_DEV void finish_direct(uint32_t* counters, uint32_t* summary) {
     if (threadIdx.x != 0) return;
     const unsigned nblocks = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
     const unsigned sub = b % DIRECT_FAN, quota = nblocks / DIRECT_FAN + (sub < nblocks % DIRECT_FAN ? 1u : 0u);  // blocks with this residue
+    __threadfence();  // release: this block's failure counts (any lane's atomics, joined by the barrier above) before its ticket
     if (atomicAdd(counters + 8 + sub, 1u) != quota - 1) return;
     const unsigned groups = nblocks < DIRECT_FAN ? nblocks : DIRECT_FAN;
     if (atomicAdd(counters + 3, 1u) != groups - 1) return;
+    __threadfence();  // acquire: every other block's counts before the summary is read
 #pragma unroll
     for (unsigned k = 0; k < DIRECT_FAN; ++k) store_handoff(counters + 8 + k, 0u);
     const uint32_t failed = load_handoff(counters), low = load_handoff(counters + 1);

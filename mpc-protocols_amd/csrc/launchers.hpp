@@ -10,7 +10,26 @@
 #include "kernels_gao.hpp"
 #include "kernels_recover.hpp"
 
+#include <atomic>
+
 namespace hbmpc {
+
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device).  Returns
+// false when the launch must not be attempted (the caller falls back to the lane kernels): a device ordinal beyond the
+// table, or the attribute call failed.  Threads that drive different contexts on one device may race here: the flag is
+// atomic and setting the attribute twice is harmless.
+constexpr int HBMPC_MAX_DEVICES = 64;
+inline bool ensure_dynamic_lds(const void* kernel, std::atomic<bool>* flags, int device, size_t lds_bytes) {
+    if (lds_bytes <= 64 * 1024) return true;
+    if (device < 0 || device >= HBMPC_MAX_DEVICES) return false;
+    if (flags[device].load(std::memory_order_acquire)) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    flags[device].store(true, std::memory_order_release);
+    return true;
+}
 
 // single-pass pruned FFT, U29, size = 2^log <= 16, cnt = d+1 coefficients
 bool launch_fft1_lo(int log, int cnt, const uint32_t* x, size_t G, int n, const uint32_t* tw, EvalOut y, hipStream_t s);

@@ -5,12 +5,8 @@ namespace hbmpc {
 namespace {
 template <int KS, bool ENCODE>
 bool launch2(const mf::MfmaGlArgs& a, unsigned grid, size_t lds, int device, hipStream_t s) {
-    static bool attr_set[64] = {};
-    if (lds > 64 * 1024 && device >= 0 && device < 64 && !attr_set[device]) {  // more than 64 KB of dynamic LDS needs the attribute
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows_gl<KS, ENCODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return false;
-        attr_set[device] = true;
-    }
+    static std::atomic<bool> attr_set[HBMPC_MAX_DEVICES];
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(&mf::k_mfma_rows_gl<KS, ENCODE>), attr_set, device, lds)) return false;
     hipLaunchKernelGGL((mf::k_mfma_rows_gl<KS, ENCODE>), dim3(grid), dim3(256), lds, s, a);
     return true;
 }

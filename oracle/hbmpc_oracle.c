@@ -16,6 +16,10 @@
  * shared Lagrange basis + per-chunk verify/recover for batch_recover_secret, FNT -> OEC -> Gao for
  * recover_secret.  Arithmetic: 4 x 64-bit-limb Montgomery (CIOS) over bls12-381 Fr, like ark-ff.
  *
+ * Compiled a second time with -DORACLE_GOLDILOCKS the same algorithms run over GoldilocksField (common/math/goldilocks.rs:4-13;
+ * exported as oracle_gl_*, elements are single u64 words): the reference's code is generic over the field, and so is
+ * everything below the field layer of this file.
+ *
  * Reference paths are relative to /root/reference/mpc/src/.
  */
 #include "hbmpc_oracle.h"
@@ -24,9 +28,12 @@
 #include <string.h>
 
 typedef unsigned __int128 u128;
+#ifndef ORACLE_GOLDILOCKS
 typedef struct {
     uint64_t l[4];
 } fr; /* Montgomery form */
+typedef U256 ELEM;
+#define ORACLE_FN(name) oracle_##name
 
 /* SURVEY.md Appendix A */
 static const uint64_t MOD[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL,
@@ -170,6 +177,69 @@ static int dom_omega(size_t n, fr* w) {
     *w = root;
     return 1;
 }
+#else
+/* ---- the small field: GoldilocksField = Fp64<MontBackend<.., 1>>, p = 2^64 - 2^32 + 1, generator 7, two-adicity 32
+ * (common/math/goldilocks.rs:4-13).  Values are kept canonical ("Montgomery form" with R = 1), an element is one u64,
+ * products go through unsigned __int128: a second, independent restatement beside oracle/spec_gl.py. ------------- */
+typedef struct {
+    uint64_t l[1];
+} fr;
+typedef uint64_t ELEM;
+#define ORACLE_FN(name) oracle_gl_##name
+static const uint64_t GL_P = 0xffffffff00000001ULL;
+static const fr ZERO = {{0}};
+static const fr ONE_M = {{1}};
+static inline fr fr_add(fr a, fr b) {
+    u128 c = (u128)a.l[0] + b.l[0];
+    if (c >= GL_P) c -= GL_P;
+    fr o = {{(uint64_t)c}};
+    return o;
+}
+static inline fr fr_sub(fr a, fr b) {
+    fr o = {{a.l[0] >= b.l[0] ? a.l[0] - b.l[0] : a.l[0] + (GL_P - b.l[0])}};
+    return o;
+}
+static inline fr fr_neg(fr a) { return fr_sub(ZERO, a); }
+static inline int fr_is_zero(fr a) { return a.l[0] == 0; }
+static inline int fr_eq(fr a, fr b) { return a.l[0] == b.l[0]; }
+static inline fr fr_mul(fr a, fr b) {
+    fr o = {{(uint64_t)(((u128)a.l[0] * b.l[0]) % GL_P)}};
+    return o;
+}
+static inline fr fr_from_canon(const ELEM* u) {
+    fr a = {{*u}};
+    return a;
+}
+static inline void fr_to_canon(fr a, ELEM* u) { *u = a.l[0]; }
+static fr fr_from_u64(uint64_t v) {
+    fr a = {{v % GL_P}};
+    return a;
+}
+static fr fr_pow_u64(fr a, uint64_t e) {
+    fr acc = ONE_M;
+    for (int i = 63; i >= 0; --i) {
+        acc = fr_mul(acc, acc);
+        if ((e >> i) & 1) acc = fr_mul(acc, a);
+    }
+    return acc;
+}
+static fr fr_inv(fr a) { return fr_pow_u64(a, GL_P - 2); }
+static size_t dom_size(size_t n) {
+    size_t s = 1;
+    while (s < n) s <<= 1;
+    return s;
+}
+static int dom_omega(size_t n, fr* w) {
+    size_t size = dom_size(n);
+    int lg = 0;
+    while (((size_t)1 << lg) < size) ++lg;
+    if (lg > 32) return 0;
+    fr root = fr_pow_u64(fr_from_u64(7), (GL_P - 1) >> 32); /* GENERATOR^((p-1)/2^32) */
+    for (int i = lg; i < 32; ++i) root = fr_mul(root, root);
+    *w = root;
+    return 1;
+}
+#endif
 /* elems[j] = omega^j, j < count */
 static int dom_elements(size_t n, size_t count, fr* elems) {
     fr w;
@@ -314,7 +384,7 @@ static void fft_inplace(fr* a, size_t size, const fr* tw /* omega^k, k < size/2 
     }
 }
 
-int oracle_compute_shares(const U256* coeffs, size_t B, size_t n, size_t d, U256* shares_out) {
+int ORACLE_FN(compute_shares)(const ELEM* coeffs, size_t B, size_t n, size_t d, ELEM* shares_out) {
     if (n <= d) return InvalidInput; /* :59-64 */
     size_t size = dom_size(n);
     fr* tw = (fr*)malloc(sizeof(fr) * (size > 1 ? size : 2));
@@ -351,7 +421,7 @@ static int vandermonde_m(size_t n, size_t d, fr* v /* [n][d+1] */) {
     free(el);
     return ShareSuccess;
 }
-int oracle_make_vandermonde(size_t n, size_t d, U256* v_out) {
+int ORACLE_FN(make_vandermonde)(size_t n, size_t d, ELEM* v_out) {
     fr* v = (fr*)malloc(sizeof(fr) * n * (d + 1));
     int rc = vandermonde_m(n, d, v);
     if (rc == ShareSuccess)
@@ -362,7 +432,7 @@ int oracle_make_vandermonde(size_t n, size_t d, U256* v_out) {
 /* ==== a5 apply_vandermonde per chunk: common/share/mod.rs:50-76, loop of batch_recon.rs:160-165.
  * The matrix is built once per call (as init_batch_reconstruct_many does), then every chunk does
  * its n x (d+1) multiply-adds including the *1 of column 0 (:68). */
-int oracle_vandermonde_apply(const U256* x, size_t G, size_t n, size_t d, U256* y_out) {
+int ORACLE_FN(vandermonde_apply)(const ELEM* x, size_t G, size_t n, size_t d, ELEM* y_out) {
     size_t m = d + 1;
     fr* v = (fr*)malloc(sizeof(fr) * n * m);
     fr* xs = (fr*)malloc(sizeof(fr) * m);
@@ -547,8 +617,8 @@ static int recover_core(poly* out, fr* at0, sh_t* shares, size_t cnt, size_t n, 
     return oec_decode(out, at0, n, t, shares, cnt, degree, el);
 }
 
-int oracle_recover_secret(const size_t* ids, const size_t* degrees, const U256* vals, size_t S, size_t n, size_t t,
-                          U256* coeffs_out, size_t* ncoeffs_out, U256* secret_out) {
+int ORACLE_FN(recover_secret)(const size_t* ids, const size_t* degrees, const ELEM* vals, size_t S, size_t n, size_t t,
+                          ELEM* coeffs_out, size_t* ncoeffs_out, ELEM* secret_out) {
     if (n < 3 * t + 1) return InvalidInput; /* :100 */
     if (S == 0) return InvalidInput;        /* :108 */
     size_t degree = degrees[0];
@@ -583,8 +653,8 @@ int oracle_recover_secret(const size_t* ids, const size_t* degrees, const U256* 
     return rc;
 }
 
-int oracle_gao_rs_decode(const U256* received, size_t k, size_t n, const size_t* erasure_positions,
-                         size_t n_erasures, U256* coeffs_out, size_t* ncoeffs_out) {
+int ORACLE_FN(gao_rs_decode)(const ELEM* received, size_t k, size_t n, const size_t* erasure_positions,
+                         size_t n_erasures, ELEM* coeffs_out, size_t* ncoeffs_out) {
     if (k > n) return InvalidInput;
     fr* el = (fr*)malloc(sizeof(fr) * n);
     if (!dom_elements(n, n, el)) {
@@ -618,8 +688,8 @@ static int cmp_snd(const void* a, const void* b) {
     return x < y ? -1 : x > y;
 }
 
-static int batch_recover_impl(const size_t* sender_ids, size_t S, const U256* evals, size_t G, size_t n, size_t d,
-                              size_t t, U256* coeffs_out, uint32_t* ncoeffs_out, uint8_t* status_out, int p0_only) {
+static int batch_recover_impl(const size_t* sender_ids, size_t S, const ELEM* evals, size_t G, size_t n, size_t d,
+                              size_t t, ELEM* coeffs_out, uint32_t* ncoeffs_out, uint8_t* status_out, int p0_only) {
     if (n < 3 * t + 1) return InvalidInput; /* :290 */
     if (S == 0) return InvalidInput;        /* :297 */
     if (G == 0) return InvalidInput;        /* :303 */
@@ -715,7 +785,8 @@ static int batch_recover_impl(const size_t* sender_ids, size_t S, const U256* ev
             poly p;
             fr at0;
             int r2 = recover_core(&p, &at0, sh, S, n, t, d, el);
-            U256 zero = {{0, 0, 0, 0}};
+            ELEM zero;
+            memset(&zero, 0, sizeof zero);
             for (size_t k = 0; k < ow; ++k) coeffs_out[c * ow + k] = zero;
             if (r2 == ShareSuccess) {
                 for (int k = 0; k < p.len && (size_t)k < ow; ++k) fr_to_canon(p.c[k], &coeffs_out[c * ow + k]);
@@ -738,18 +809,18 @@ static int batch_recover_impl(const size_t* sender_ids, size_t S, const U256* ev
     return first_err;
 }
 
-int oracle_batch_recover(const size_t* sender_ids, size_t S, const U256* evals, size_t G, size_t n, size_t d,
-                         size_t t, U256* coeffs_out, uint32_t* ncoeffs_out, uint8_t* status_out) {
+int ORACLE_FN(batch_recover)(const size_t* sender_ids, size_t S, const ELEM* evals, size_t G, size_t n, size_t d,
+                         size_t t, ELEM* coeffs_out, uint32_t* ncoeffs_out, uint8_t* status_out) {
     return batch_recover_impl(sender_ids, S, evals, G, n, d, t, coeffs_out, ncoeffs_out, status_out, 0);
 }
-int oracle_batch_recover_p0(const size_t* sender_ids, size_t S, const U256* evals, size_t G, size_t n, size_t d,
-                            size_t t, U256* secrets_out, uint8_t* status_out) {
+int ORACLE_FN(batch_recover_p0)(const size_t* sender_ids, size_t S, const ELEM* evals, size_t G, size_t n, size_t d,
+                            size_t t, ELEM* secrets_out, uint8_t* status_out) {
     return batch_recover_impl(sender_ids, S, evals, G, n, d, t, secrets_out, NULL, status_out, 1);
 }
 
 /* ==== NonRobustShare::recover_secret: shamir.rs:199-239 ====================================== */
-int oracle_nonrobust_recover_secret(const size_t* ids, const size_t* degrees, const U256* vals, size_t S, size_t n,
-                                    U256* coeffs_out, size_t* ncoeffs_out, U256* secret_out) {
+int ORACLE_FN(nonrobust_recover_secret)(const size_t* ids, const size_t* degrees, const ELEM* vals, size_t S, size_t n,
+                                    ELEM* coeffs_out, size_t* ncoeffs_out, ELEM* secret_out) {
     if (S == 0) return InvalidInput;
     for (size_t i = 0; i < S; ++i)
         for (size_t j = i + 1; j < S; ++j)
@@ -780,7 +851,8 @@ int oracle_nonrobust_recover_secret(const size_t* ids, const size_t* degrees, co
     if (rc == ShareSuccess) {
         for (int i = 0; i < p.len; ++i) fr_to_canon(p.c[i], &coeffs_out[i]);
         *ncoeffs_out = (size_t)p.len;
-        U256 zero = {{0, 0, 0, 0}};
+        ELEM zero;
+            memset(&zero, 0, sizeof zero);
         *secret_out = zero; /* reference indexes poly[0]: panics on the zero polynomial */
         if (p.len > 0) fr_to_canon(p.c[0], secret_out);
     }
@@ -791,14 +863,19 @@ int oracle_nonrobust_recover_secret(const size_t* ids, const size_t* degrees, co
 }
 
 /* ==== element-wise (a9, a11, a12, a13).  Canonical in, canonical out. ======================== */
-static inline fr ld(const U256* u) {
+#ifndef ORACLE_GOLDILOCKS
+static inline fr ld(const ELEM* u) {
     fr a = {{u->data[0], u->data[1], u->data[2], u->data[3]}};
     return a;
 } /* canonical value used directly where only add/sub are needed */
-static inline void st(fr a, U256* u) { memcpy(u->data, a.l, 32); }
+static inline void st(fr a, ELEM* u) { memcpy(u->data, a.l, 32); }
+#else
+static inline fr ld(const ELEM* u) { return fr_from_canon(u); }
+static inline void st(fr a, ELEM* u) { *u = a.l[0]; }
+#endif
 
 /* triple_generation.rs:333-340 */
-int oracle_triple_local(const U256* a, const U256* b, const U256* r2t, size_t N, U256* out) {
+int ORACLE_FN(triple_local)(const ELEM* a, const ELEM* b, const ELEM* r2t, size_t N, ELEM* out) {
     for (size_t i = 0; i < N; ++i) {
         fr p = fr_mul(fr_from_canon(&a[i]), ld(&b[i])); /* (aR)*b/R = ab, canonical */
         st(fr_sub(p, ld(&r2t[i])), &out[i]);
@@ -806,13 +883,13 @@ int oracle_triple_local(const U256* a, const U256* b, const U256* r2t, size_t N,
     return ShareSuccess;
 }
 /* triple_generation.rs:196-208 */
-int oracle_triple_finalize(const U256* rt, const U256* opened, size_t N, U256* c_out) {
+int ORACLE_FN(triple_finalize)(const ELEM* rt, const ELEM* opened, size_t N, ELEM* c_out) {
     for (size_t i = 0; i < N; ++i) st(fr_add(ld(&rt[i]), ld(&opened[i])), &c_out[i]);
     return ShareSuccess;
 }
 /* multiplication.rs:417-426 */
-int oracle_beaver_open_shares(const U256* a, const U256* b, const U256* x, const U256* y, size_t N, U256* d_sh,
-                              U256* e_sh) {
+int ORACLE_FN(beaver_open_shares)(const ELEM* a, const ELEM* b, const ELEM* x, const ELEM* y, size_t N, ELEM* d_sh,
+                              ELEM* e_sh) {
     for (size_t i = 0; i < N; ++i) {
         st(fr_sub(ld(&a[i]), ld(&x[i])), &d_sh[i]);
         st(fr_sub(ld(&b[i]), ld(&y[i])), &e_sh[i]);
@@ -820,8 +897,8 @@ int oracle_beaver_open_shares(const U256* a, const U256* b, const U256* x, const
     return ShareSuccess;
 }
 /* multiplication.rs:57-100 */
-int oracle_beaver_finalize(const U256* c, const U256* x, const U256* y, const U256* d, const U256* e, size_t N,
-                           U256* z_out) {
+int ORACLE_FN(beaver_finalize)(const ELEM* c, const ELEM* x, const ELEM* y, const ELEM* d, const ELEM* e, size_t N,
+                           ELEM* z_out) {
     for (size_t i = 0; i < N; ++i) {
         fr dm = fr_from_canon(&d[i]), em = fr_from_canon(&e[i]);
         fr de = fr_mul(dm, ld(&e[i]));
@@ -831,10 +908,11 @@ int oracle_beaver_finalize(const U256* c, const U256* x, const U256* y, const U2
     }
     return ShareSuccess;
 }
+#ifndef ORACLE_GOLDILOCKS /* TruncPr's byte logic is written for the 256-bit field (the reference's fpmul runs over Fr) */
 /* fpmul/mod.rs:377 */
 static fr pow2_m(size_t e) { return fr_pow_u64(fr_from_u64(2), (uint64_t)e); }
 /* truncpr.rs:277-283 */
-int oracle_truncpr_rdash(const U256* r_bits, size_t m, size_t N, U256* r_dash_out) {
+int ORACLE_FN(truncpr_rdash)(const ELEM* r_bits, size_t m, size_t N, ELEM* r_dash_out) {
     for (size_t i = 0; i < N; ++i) {
         fr acc = ZERO;
         for (size_t j = 0; j < m; ++j) acc = fr_add(acc, fr_mul(pow2_m(j), ld(&r_bits[j * N + i])));
@@ -843,8 +921,8 @@ int oracle_truncpr_rdash(const U256* r_bits, size_t m, size_t N, U256* r_dash_ou
     return ShareSuccess;
 }
 /* truncpr.rs:275,294-297 */
-int oracle_truncpr_open_share(const U256* a, const U256* r_dash, const U256* r_int, size_t k, size_t m, size_t N,
-                              U256* open_out) {
+int ORACLE_FN(truncpr_open_share)(const ELEM* a, const ELEM* r_dash, const ELEM* r_int, size_t k, size_t m, size_t N,
+                              ELEM* open_out) {
     if (k == 0) return InvalidInput; /* 2^(k-1): usize underflow panics in the reference */
     fr one = {{1, 0, 0, 0}};
     fr p2k = fr_mul(pow2_m(k - 1), one); /* canonical */
@@ -869,8 +947,8 @@ static fr mod_pow_2(fr x, size_t m) {
     return o;
 }
 /* truncpr.rs:215-220 */
-int oracle_truncpr_finalize(const U256* a, const U256* r_dash, const U256* c_open, size_t m, size_t N,
-                            U256* d_out) {
+int ORACLE_FN(truncpr_finalize)(const ELEM* a, const ELEM* r_dash, const ELEM* c_open, size_t m, size_t N,
+                            ELEM* d_out) {
     if (m % 8 != 0 && m / 8 >= 32) return InvalidInput; /* bytes[full_bytes] out of bounds: reference panics */
     fr inv2m = fr_inv(pow2_m(m));
     for (size_t i = 0; i < N; ++i) {
@@ -881,29 +959,32 @@ int oracle_truncpr_finalize(const U256* a, const U256* r_dash, const U256* c_ope
     return ShareSuccess;
 }
 
+#endif
+
 /* ---- raw field ops for cross-checking the device arithmetic ---------------------------------- */
-void oracle_fr_mul(const U256* a, const U256* b, size_t N, U256* out) {
+void ORACLE_FN(fr_mul)(const ELEM* a, const ELEM* b, size_t N, ELEM* out) {
     for (size_t i = 0; i < N; ++i) st(fr_mul(fr_from_canon(&a[i]), ld(&b[i])), &out[i]);
 }
-void oracle_fr_add(const U256* a, const U256* b, size_t N, U256* out) {
+void ORACLE_FN(fr_add)(const ELEM* a, const ELEM* b, size_t N, ELEM* out) {
     for (size_t i = 0; i < N; ++i) st(fr_add(ld(&a[i]), ld(&b[i])), &out[i]);
 }
-void oracle_fr_sub(const U256* a, const U256* b, size_t N, U256* out) {
+void ORACLE_FN(fr_sub)(const ELEM* a, const ELEM* b, size_t N, ELEM* out) {
     for (size_t i = 0; i < N; ++i) st(fr_sub(ld(&a[i]), ld(&b[i])), &out[i]);
 }
-void oracle_fr_inv(const U256* a, size_t N, U256* out) {
+void ORACLE_FN(fr_inv)(const ELEM* a, size_t N, ELEM* out) {
     for (size_t i = 0; i < N; ++i) fr_to_canon(fr_inv(fr_from_canon(&a[i])), &out[i]);
 }
-void oracle_domain_elements(size_t n, size_t count, U256* out) {
+void ORACLE_FN(domain_elements)(size_t n, size_t count, ELEM* out) {
     fr* el = (fr*)malloc(sizeof(fr) * (count ? count : 1));
     if (dom_elements(n, count, el))
         for (size_t i = 0; i < count; ++i) fr_to_canon(el[i], &out[i]);
     free(el);
 }
 
+#ifndef ORACLE_GOLDILOCKS
 /* SplitMix64(seed) -> 4 limbs -> mod r  (SURVEY.md section 8(d)); conditional subtractions reduce a
  * 256-bit value below r (2^256 < 5r). */
-void oracle_fill_random(uint64_t seed, size_t N, U256* out) {
+void ORACLE_FN(fill_random)(uint64_t seed, size_t N, ELEM* out) {
     uint64_t s = seed;
     for (size_t i = 0; i < N; ++i) {
         uint64_t l[4];
@@ -918,3 +999,20 @@ void oracle_fill_random(uint64_t seed, size_t N, U256* out) {
         memcpy(out[i].data, l, 32);
     }
 }
+#else
+/* SplitMix64(seed) -> one word, redrawn while >= p (uniform on the field) */
+void oracle_gl_fill_random(uint64_t seed, size_t N, ELEM* out) {
+    uint64_t s = seed;
+    for (size_t i = 0; i < N; ++i) {
+        uint64_t v;
+        do {
+            s += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = s;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            v = z ^ (z >> 31);
+        } while (v >= GL_P);
+        out[i] = v;
+    }
+}
+#endif

@@ -410,3 +410,30 @@ def test_small_field_triple_encode_fused_equals_two_launches(_eng, n, t, G, part
         assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, 0, y3.data_ptr()) == 0
         eng.sync()
         assert torch.equal(y3, y1)
+
+
+@pytest.mark.parametrize("n,t,d,G", [(16, 5, 5, 1 << 15), (16, 5, 10, 20011), (31, 10, 10, 1 << 14), (64, 21, 21, 4099)])
+def test_against_the_c_restatement_at_size(_eng, n, t, d, G):
+    """hbmpc_gl_* against oracle/hbmpc_oracle.c built for Goldilocks (oracle/cref_gl.py) -- the second, independent
+    restatement of the small field -- at batch sizes the Python big-int oracle does not reach: every chunk of an encode
+    and of a decode with corrupted, missing and failing chunks, status bytes and trimmed lengths included."""
+    from oracle import cref_gl as CG
+    x = CG.fill_random(0xC0FFEE02 + n + d, G * (d + 1)).reshape(G, d + 1)
+    rc, y = _eng.vandermonde_apply(x, n, d)
+    rc0, y0 = CG.vandermonde_apply(x, n, d)
+    assert rc == rc0 == 0 and np.array_equal(y, y0)
+    rc, sh = _eng.compute_shares(x, n, d)
+    assert rc == 0 and np.array_equal(sh, CG.compute_shares(x, n, d)[1])
+    rng = np.random.default_rng(n * 1000 + d)
+    ids = list(rng.permutation(n)[: max(d + t + 1, n - 1)])           # arrival order, one sender missing when possible
+    ev = np.ascontiguousarray(y[ids])
+    S_ = len(ids)
+    bad = rng.choice(G, G // 8, replace=False)
+    for j, g in enumerate(bad):
+        k = 1 + j % (t + 1)                                           # 1 .. t + 1 corrupted senders: the last kind cannot decode
+        for s in rng.choice(S_, min(k, S_), replace=False):
+            ev[s, g] = (int(ev[s, g]) + 1 + j) % P
+    rc, co, nco, st = _eng.batch_recover([int(i) for i in ids], ev, n, d, t)
+    rc0, co0, nco0, st0 = CG.batch_recover([int(i) for i in ids], ev, n, d, t)
+    assert rc == rc0 and np.array_equal(st, st0) and np.array_equal(nco, nco0) and np.array_equal(co, co0)
+    assert (st == 1).any() and (st == 0).sum() >= G - len(bad)
