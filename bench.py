@@ -930,6 +930,29 @@ def goldilocks_measurements(torch, dev, stream, ev_time):
     res["gl_cfg4_triple_gen_16_parties"] = {"triples_per_s": N / ms * 1e3, "ms": ms, "triples": N}
     tg.close()
     eng.close()
+    # the CPU figure of the small-field rows: the C restatement built for Goldilocks (oracle/cref_gl.py, "port"), one thread,
+    # a bounded sample; like every oracle use in this file it is a reported baseline and a checker, never the thing timed above
+    from oracle import cref_gl
+    smp = 1 << 18
+    xs = cref_gl.fill_random(0xC0FFEE05, smp * 6).reshape(smp, 6)
+    t0, reps = time.perf_counter(), 0
+    while reps < 64 and time.perf_counter() - t0 < 2.0:
+        assert cref_gl.compute_shares(xs, 16, 5)[0] == 0
+        reps += 1
+    dt = time.perf_counter() - t0
+    res["gl_cpu_baseline_compute_shares"] = {"value": 16 * smp * reps / dt, "unit": "shares/s", "cores": 1, "kind": "port",
+                                             "sample": f"compute_shares n=16 d=5 over Goldilocks: {reps} passes over {smp} secrets, single thread"}
+    xr = cref_gl.fill_random(0xC0FFEE06, (1 << 14) * 11).reshape(1 << 14, 11)
+    rc, yr = cref_gl.vandermonde_apply(xr, 31, 10)
+    t0, reps = time.perf_counter(), 0
+    while reps < 64 and time.perf_counter() - t0 < 2.0:
+        rc, co, _, st = cref_gl.batch_recover(list(range(31)), yr, 31, 10, 10)
+        assert rc == 0
+        reps += 1
+    dt = time.perf_counter() - t0
+    assert np.array_equal(co, xr)
+    res["gl_cpu_baseline_batch_recover"] = {"value": (1 << 14) * reps / dt, "unit": "recons/s", "cores": 1, "kind": "port",
+                                            "sample": f"batch_recover n=31 d=t=10 over Goldilocks: {reps} passes over 16384 chunks, single thread"}
     return res
 
 

@@ -206,14 +206,15 @@ struct MfmaRowsArgs {
     MfmaRole role[MF_MAX_ROLES];
     int direct;           // 1 (decode, ONE role): no OEC round exists, a chunk that fails the verification fails for good and this
                           // kernel is the whole call (kernels_recover.hpp: fail_chunk / count_failures / finish_direct)
-    int abl;              // microbenchmark ablations (tools/ubench_mfma.hip), 0 in the library: 1 = no epilogue arithmetic (loads and stores stay),
-                          // 2 = no MFMAs, 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored
 };
 
 // NR > 0: every role of the launch has at most NR rows and the row loop is unrolled NR times with a compile-time trip
 // count -- hipcc can then count the stores issued after the next tile's loads and wait with vmcnt(#stores) at the tile
 // boundary; with a run-time trip count it waits for vmcnt(0), i.e. for every store of the tile to complete.
-template <int M, int CG, int WAVES, int NR = 0>
+// ABL: timing-only ablations, instantiated by tools/ubench_mfma.hip alone (the library's instances have ABL = 0 and none
+// of that code): 1 = no epilogue arithmetic (loads and stores stay), 2 = no MFMAs, 4 = every tile re-reads the first tiles
+// (inputs stay in L2) and nothing is stored.
+template <int M, int CG, int WAVES, int NR = 0, int ABL = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     static_assert(M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp) and the sum below 2^273");
     constexpr int ROWB = M * 1024 + 128;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     auto tile_chunks = [&](size_t t, uint32_t (&gg)[CG]) {
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
-            const size_t gi = ((a.abl & 4) ? (t & 63) * CG + cg : t * CG + cg) * 32 + c;
+            const size_t gi = ((ABL & 4) ? (t & 63) * CG + cg : t * CG + cg) * 32 + c;
             gg[cg] = (uint32_t)(gi < a.G ? gi : a.G - 1);
         }
     };
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
         tile_chunks(t, g);
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
-            live[cg] = (((a.abl & 4) ? (t & 63) * CG + cg : t * CG + cg) * 32 + c) < a.G;
+            live[cg] = (((ABL & 4) ? (t & 63) * CG + cg : t * CG + cg) * 32 + c) < a.G;
 #pragma unroll
             for (int i = 0; i < M; ++i) data[cg][i] = flip(data[cg][i]);
         }
@@ -306,9 +307,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                 for (int k = 0; k < 4; ++k) bias[k] = b0[k], bias[4 + k] = b1[k], bias[8 + k] = b2[k], bias[12 + k] = b3[k];
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) acc[cg] = bias;
-                if (!(a.abl & 2)) mfma_row<M, CG>(cur + lane * 16, data, acc);
+                if (!(ABL & 2)) mfma_row<M, CG>(cur + lane * 16, data, acc);
             }
-            if ((a.abl & 1) && r < nver) {
+            if ((ABL & 1) && r < nver) {
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) bad[cg] |= (uint32_t)acc[cg][0] & (uint32_t)acc[cg][7] & (uint32_t)ys_cur[cg][0] & 0x80000000u;  // digit sums are < 2^24
                 if (r + 1 < nver) {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                 }
             } else if (r < nver) {
 #pragma unroll
-                for (int cg = 0; cg < CG; ++cg) bad[cg] |= verify_tile(acc[cg], ys_cur[cg], H) & (a.abl ? 0u : ~0u);
+                for (int cg = 0; cg < CG; ++cg) bad[cg] |= verify_tile(acc[cg], ys_cur[cg], H) & (ABL ? 0u : ~0u);
                 if (r + 1 < nver) {
 #pragma unroll
                     for (int cg = 0; cg < CG; ++cg) ys_cur[cg] = ys_next[cg];
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
                     uint32_t Rw[4];
-                    if (a.abl & 1) Rw[0] = acc[cg][0], Rw[1] = acc[cg][5], Rw[2] = acc[cg][10], Rw[3] = acc[cg][15];  // no arithmetic, same stores
+                    if (ABL & 1) Rw[0] = acc[cg][0], Rw[1] = acc[cg][5], Rw[2] = acc[cg][10], Rw[3] = acc[cg][15];  // no arithmetic, same stores
                     else reduce_tile(acc[cg], Rw, H);
                     if (a.direct) {  // one role, the verify rows are behind us: a chunk that failed them gets zeros
                         const unsigned long long mb = __ballot(bad[cg] != 0);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
                     }
                     uint8_t* qb = a.out_party_major ? a.out + k * a.out_stride * 32 : a.out + k * 32;  // wave-uniform
                     const uint32_t qo = g[cg] * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
-                    if (live[cg] && (!(a.abl & 4) || Rw[0] == 0x12345u)) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+                    if (live[cg] && (!(ABL & 4) || Rw[0] == 0x12345u)) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
                 }
             }
         }
@@ -377,7 +378,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     v4i setA[CG][M], setB[CG][M];
     size_t t = (size_t)wg_in_role * WAVES + wave;
     if (t < ntiles) load_inputs(t, setA);
-    const bool pf = !(a.abl & 8);
     while (t < ntiles) {
         if (t + tstep < ntiles) load_inputs(t + tstep, setB);
         process_tile(t, setA);
@@ -387,7 +387,6 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
         process_tile(t, setB);
         t += tstep;
     }
-    (void)pf;
     if (a.direct) finish_direct(a.counters, a.summary);
 }
 

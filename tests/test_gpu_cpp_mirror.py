@@ -57,7 +57,18 @@ def test_pool_allocated_caller_buffers():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     p = subprocess.run([bin_], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "pool buffers passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
-    # the configuration the header warns about (the pool returns memory to the driver at every sync): recorded, not
-    # asserted -- on ROCm 7.2 / gfx950 every second episode reads stale lines, which no library code can prevent
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="UNSUPPORTED configuration (include/hbmpc_hip.h, 'Device buffers'): a hipMallocAsync pool at its default "
+                                        "release threshold returns memory to the driver at every synchronisation; on ROCm 7.2 / gfx950 blocks it "
+                                        "re-acquires are then read through stale cache lines (every second episode wrong, "
+                                        "profiles/r02_pool_buffers_default_threshold.txt) -- nothing a library can detect or prevent")
+def test_pool_allocated_caller_buffers_default_release_threshold():
+    """the same episodes with the pool's DEFAULT release threshold: recorded as an expected failure (an XPASS means the
+    platform no longer shows the stale lines), so that the outcome is in the test report instead of a print"""
+    bin_ = os.path.join(ROOT, "tests", "cpp", "test_pool_buffers")
+    if not os.path.exists(bin_):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     q = subprocess.run([bin_], capture_output=True, text=True, timeout=600, env=dict(os.environ, POOL_DEFAULT_THRESHOLD="1"))
-    print("default release threshold:", "passed" if q.returncode == 0 else q.stdout.strip().splitlines()[-1])
+    assert q.returncode == 0, q.stdout.strip().splitlines()[-1] if q.stdout.strip() else q.stderr[-500:]

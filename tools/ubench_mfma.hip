@@ -53,7 +53,7 @@ static float time_ms(F f, int reps) {
 }
 
 static int g_nwg = 256;  // workgroups per launch (one per CU: the table rows of a role fill most of the LDS)
-template <int M, int CG, int WAVES, int NR = 0>
+template <int M, int CG, int WAVES, int NR = 0, int ABL = 0>
 static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     constexpr int ROWB = M * 1024 + 128;
     const int cap = (160 * 1024) / ROWB;
@@ -73,14 +73,14 @@ static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES, NR, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (NR > 0 && mf::mf_max_role_rows(a) > NR) {
         fprintf(stderr, "role rows %d exceed the static row count %d\n", mf::mf_max_role_rows(a), NR);
         exit(2);
     }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES, NR>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES, NR, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 // encode x[G][M] with [I ; Cv] -> evals[M + nv][G]; decode with verify rows Cv and output rows Co; check vs host
@@ -227,18 +227,13 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
     CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
     if (G > 100000) {
         fprintf(stderr, "   ablation %s CG=%d waves=%d: full %.4f ms", name, CG, WAVES, ms_dec);
-        for (int abl : {1, 2, 3, 4, 5, 6, 7}) {
-            mf::MfmaRowsArgs rb = ra;
-            rb.abl = abl;
-            fprintf(stderr, " | abl %d: %.4f", abl, time_ms([&] { launch_rows<M, CG, WAVES>(rb, nv + M); }, reps));
-        }
+#define HBMPC_ABL_RUN(A, args, rows) fprintf(stderr, " | abl %d: %.4f", A, time_ms([&] { launch_rows<M, CG, WAVES, 0, A>(args, rows); }, reps))
+        HBMPC_ABL_RUN(1, ra, nv + M); HBMPC_ABL_RUN(2, ra, nv + M); HBMPC_ABL_RUN(3, ra, nv + M); HBMPC_ABL_RUN(4, ra, nv + M);
+        HBMPC_ABL_RUN(5, ra, nv + M); HBMPC_ABL_RUN(6, ra, nv + M); HBMPC_ABL_RUN(7, ra, nv + M);
         fprintf(stderr, "   (1 = no epilogue arithmetic, 2 = no MFMA, 3 = memory traffic only, 4 = inputs from L2 + no stores)\n");
         fprintf(stderr, "   encode ablation %s CG=%d waves=%d: full %.4f ms", name, CG, WAVES, ms_enc);
-        for (int abl : {1, 2, 3, 4, 5, 6, 7}) {
-            mf::MfmaRowsArgs eb = ea;
-            eb.abl = abl;
-            fprintf(stderr, " | abl %d: %.4f", abl, time_ms([&] { launch_rows<M, CG, WAVES>(eb, n); }, reps));
-        }
+        HBMPC_ABL_RUN(1, ea, n); HBMPC_ABL_RUN(2, ea, n); HBMPC_ABL_RUN(3, ea, n); HBMPC_ABL_RUN(4, ea, n);
+        HBMPC_ABL_RUN(5, ea, n); HBMPC_ABL_RUN(6, ea, n); HBMPC_ABL_RUN(7, ea, n);
         fprintf(stderr, "\n");
         CK(hipMemcpy(cnt, d_cnt, 16, hipMemcpyDeviceToHost));
     }
