@@ -395,6 +395,9 @@ def main():
                     help="cfg2+cfg3 (default): the two halves of BASELINE.json's metric, 2^20 secrets / chunks per GPU "
                          "(weak scaling).  cfg4 / cfg5: the triple_gen / fpmul pipelines of BASELINE configs[3] / [4], their "
                          "fixed batch sharded over the ranks (strong scaling)")
+    ap.add_argument("--with-producers", action="store_true",
+                    help="--workload cfg4: time run_preprocessing's whole triple part -- RanSha (a, b), DouSha + RanDouSha ([r]_t, [r]_2t) "
+                         "and the triple generation -- device-resident from the dealers' polynomials to [c]_t")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-final-gather", action="store_true",
                     help="N > 1: skip the all-gather of the shares after the timed region (the path's only collective)")
@@ -627,7 +630,32 @@ def bench_pipeline(ctx):
     pl = load_package().pipelines
     n, t = 16, 5
     torch.manual_seed(0xC0FFEE03 + rank)
-    if args.workload == "cfg4":
+    pre = None
+    if args.workload == "cfg4" and args.with_producers:
+        m = 2 * t + 1
+        groups = (1 << 22) // m
+        lo, hi = shard_range(groups, rank, world)
+        N = (hi - lo) * m
+        pre = pl.Preprocessing(eng, n, t, N, stream)
+        tg = pre.tg
+        # the dealers' polynomials (what each party's rng would draw), filled on the device; DouSha deals BOTH sharings of one secret
+        sec0 = {}
+        for ptr, K, deg in ((pre.rs.coeffs, pre.K_rs, t), (pre.rd.coeffs_t, pre.K_rd, t), (pre.rd.coeffs_2t, pre.K_rd, 2 * t)):
+            for p in range(n):   # dealer by dealer: bounds the temporary
+                co = _rand_fr(torch, dev, K, deg + 1)
+                if ptr == pre.rd.coeffs_2t:
+                    co[:, 0] = sec0[p]
+                elif ptr == pre.rd.coeffs_t:
+                    sec0[p] = co[:, 0].clone()
+                eng.d2d(ptr + p * K * (deg + 1) * 32, co.data_ptr(), K * (deg + 1) * 32, stream)
+                torch.cuda.synchronize()
+                del co
+        del sec0
+        pre.run(check=True)                           # verifiers say OK, every decode reports zero failures
+        step, total, unit, pipe, result_ptr = (lambda: pre.run(check=False)), groups * m, "triples/s", pre, tg.c
+        what = (f"run_preprocessing's triple part n={n} t={t}: RanSha ({pre.K_rs} batch elements per dealer -> a, b), DouSha + RanDouSha "
+                f"({pre.K_rd} -> [r]_t, [r]_2t), triple_gen of {groups * m} Beaver triples, {N} on this rank, from the dealers' polynomials")
+    elif args.workload == "cfg4":
         m = 2 * t + 1
         groups = (1 << 22) // m                      # chunks of 2t+1 triples (BatchRecon's unit)
         lo, hi = shard_range(groups, rank, world)
@@ -701,6 +729,29 @@ def bench_pipeline(ctx):
     if trec:
         out["roofline"]["traffic"] = trec["hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = trec["source"]
+    if pre is not None:
+        # the producers alone (their share of the step), and their compulsory traffic: deal (coefficients in, n^2 K shares out),
+        # transpose + n x n Vandermonde (n^2 K in and out, each), the verifiers' reads, the output slices
+        def ev_ms(fn):
+            a0, a1, r = ctx["events"]()
+            fn()
+            torch.cuda.synchronize()
+            r(a0)
+            for _ in range(args.steps):
+                fn()
+            r(a1)
+            torch.cuda.synchronize()
+            return a0.elapsed_time(a1) / args.steps
+        Krs, Krd = pre.K_rs, pre.K_rd
+        rs_b = (n * Krs * (t + 1) + 5 * n * n * Krs + 2 * t * ((2 * t + 1) * Krs + Krs * (t + 1)) + 2 * n * (n - 2 * t) * Krs) * 32
+        rd_b = (n * Krd * (3 * t + 2) + 10 * n * n * Krd + (n - t - 1) * 4 * n * Krd + 4 * n * (t + 1) * Krd) * 32
+        rs_ms, rd_ms = ev_ms(lambda: pre.rs.run(check=False)), ev_ms(lambda: pre.rd.run(check=False))
+        out["producers"] = {"ransha_ms": rs_ms, "ransha_algorithmic_bytes": rs_b, "ransha_GBps": rs_b / rs_ms / 1e6,
+                            "randousha_ms": rd_ms, "randousha_algorithmic_bytes": rd_b, "randousha_GBps": rd_b / rd_ms / 1e6,
+                            "batch_elements_per_dealer": {"ransha": Krs, "randousha": Krd}}
+        out["roofline"]["step_algorithmic_bytes"] = step_bytes + rs_b + rd_b
+        out["roofline"]["step_GBps"] = (step_bytes + rs_b + rd_b) / (tm["kernel_ms"] * 1e-3) / 1e9
+        out["roofline"]["step_frac"] = out["roofline"]["step_GBps"] / HBM_PEAK_GBS
     if world > 1 and not args.no_final_gather:
         from mpc_protocols_amd import sharding
         # this rank's result shares as a torch view of the pipeline's device buffer: [n][N][4]

@@ -286,6 +286,25 @@ ShareErrorCode hbmpc_dev_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, si
                                            size_t row_stride, size_t G, size_t n, U256* coeffs_out_dev,
                                            uint32_t* degree_out_dev, void* stream);
 
+/* ---- layout and verdict steps of the preprocessing producers (RanSha, DouSha, RanDouSha; either field: the element
+ * size follows the context) -----------------------------------------------------------------------------------------
+ * The producers of config 4's inputs are Vandermonde products and verifier interpolations the calls above already cover
+ * (make_vandermonde(n, n - 1) + apply_vandermonde: share_gen/share_gen.rs:415-419, ran_dou_sha/mod.rs:392-403;
+ * recover_secret + degree test: share_gen.rs:516-530; NonRobustShare::recover_secret x 2 + the exact-degree / equal-secret
+ * tests: ran_dou_sha/mod.rs:569-602).  What they add is data movement between "who dealt" and "who received" -- in the
+ * reference the network, here a transpose -- and the verifiers' verdicts, kept on the device:
+ *   transpose       dst[b][c][r] = src[b][r][c] (strides in elements)
+ *   check_degree    bad[0] += number of polynomials (coeffs[G][m], not trimmed) whose DensePolynomial::degree() is not
+ *                   want_degree or whose status byte (nullable; from hbmpc_dev_batch_recover) is a failure; bad[1] =
+ *                   min(bad[1], first such polynomial).  The caller zeroes bad[0] and sets bad[1] = 0xffffffff.
+ *   check_double_share   the same for pairs: degree t, degree 2t and equal constant terms */
+ShareErrorCode hbmpc_dev_transpose(hbmpc_ctx* ctx, const void* src_dev, size_t rows, size_t cols, size_t src_row_stride, void* dst_dev,
+                                   size_t dst_row_stride, size_t batch, size_t src_batch_stride, size_t dst_batch_stride, void* stream);
+ShareErrorCode hbmpc_dev_check_degree(hbmpc_ctx* ctx, const void* coeffs_dev, const uint8_t* status_dev, size_t G, size_t m,
+                                      size_t want_degree, uint32_t* bad_dev, void* stream);
+ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const void* coeffs_t_dev, const void* coeffs_2t_dev, size_t G, size_t m,
+                                            size_t t, uint32_t* bad_dev, void* stream);
+
 /* ==== a9/a11/a12/a13: element-wise share arithmetic of one party ============================
  * All arrays hold N elements of ONE party (same id, same degree: the id/degree checks of
  * common/mod.rs:167-300 are metadata and stay with the host mirror).  Host-pointer calls;

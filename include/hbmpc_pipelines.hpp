@@ -8,6 +8,11 @@
 //               triple_gen/triple_generation.rs:304-364,164-232; batch_recon/batch_recon.rs:144-185,332-481
 //   FpMul       FPMulNode::init = Multiply (Beaver, RBC path) + TruncPrNode
 //               fpmul/fpmul.rs:61-110, mul/multiplication.rs:417-426,57-139, fpmul/truncpr.rs:185-318
+//   RanSha      RanShaNode: deal, n x n Vandermonde, verifier reconstruction + degree test, output slice
+//               share_gen/share_gen.rs:232-289,401-454,516-530,199-203
+//   RanDouSha   DouShaNode deal + RanDouShaNode: both Vandermonde products, verifier interpolations + tests, output slice
+//               double_share/double_share_generation.rs:151-215, ran_dou_sha/mod.rs:371-449,569-602,314-331
+//   Preprocessing   run_preprocessing's triple part (honeybadger/mod.rs:1239-1393): RanSha -> a, b; RanDouSha -> r; TripleGen
 //
 // run() only ENQUEUES on the stream; after one eager run the same call sequence can be captured into a HIP graph
 // (capture()) and replayed (replay()) -- at the batch sizes the protocols really use that removes the launch
@@ -187,6 +192,164 @@ class FpMul : public CapturablePipeline {
     U256 *desh_, *rdash_, *osh_, *dop_, *eop_, *cop_;
     uint8_t* status_;
     std::vector<size_t> ids_;
+};
+
+// What RanSha and RanDouSha share.  The dealers' polynomials are the INPUT (coefficient rows [dealer][K][deg + 1], column 0 the
+// secret: uploaded by the host or filled on the device by hbmpc_dev_fill_coeffs -- the reference draws them from each party's rng).
+// Layouts (all n parties on one device): dealt S[p][j, k] --transpose--> x[j, k][p] --n x n Vandermonde--> y[i][j, k]; what party j
+// sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied.
+class Producer : public CapturablePipeline {
+  protected:
+    Producer(hbmpc_ctx* ctx, size_t n, size_t t, size_t K, void* stream) : CapturablePipeline(ctx, stream), n_(n), t_(t), K_(K) {}
+    void deal(const U256* coeffs, size_t deg, U256* S) {
+        for (size_t p = 0; p < n_; ++p)  // dealer p: compute_shares of its K polynomials
+            pl_check(hbmpc_dev_compute_shares(ctx_, coeffs + p * K_ * (deg + 1), K_, n_, deg, S + p * n_ * K_, stream_), ctx_, "deal");
+    }
+    void mix(const U256* S, U256* x, U256* y) {
+        pl_check(hbmpc_dev_transpose(ctx_, S, n_, n_ * K_, n_ * K_, x, n_, 1, 0, 0, stream_), ctx_, "dealt shares -> recipients");
+        pl_check(hbmpc_dev_vandermonde_apply(ctx_, x, n_ * K_, n_, n_ - 1, y, stream_), ctx_, "n x n Vandermonde");
+    }
+    void clear_bad(uint32_t* bad) {
+        static const uint32_t init[2] = {0u, 0xffffffffu};
+        pl_check(hbmpc_memcpy_h2d(ctx_, bad, init, sizeof init, stream_), ctx_, "h2d");
+    }
+    size_t n_, t_, K_;
+
+  public:
+    // {number of verifier checks that failed, first failing batch element}: zero means every verifier says OK
+    void verdict(const uint32_t* bad_dev, uint32_t out[2]) {
+        pl_check(hbmpc_memcpy_d2h(ctx_, out, bad_dev, 8, stream_), ctx_, "d2h");
+        sync();
+    }
+};
+
+// K batch elements per dealer -> (n - 2t) K random degree-t sharings per party, verified by parties 0 .. 2t - 1 from the
+// shares of the first verify_senders parties (0 = the default 2t + 1: the handler fires when that many have arrived,
+// share_gen.rs:497 -- with degree t a decode with no OEC round)
+class RanSha : public Producer {
+  public:
+    RanSha(hbmpc_ctx* ctx, size_t n, size_t t, size_t K, void* stream, size_t verify_senders = 0)
+        : Producer(ctx, n, t, K, stream), nout((n - 2 * t) * K),
+          arena_(ctx, (n * K * (t + 1) + 3 * n * n * K + K * (t + 1) + n * (n - 2 * t) * K) * 32 + K + (1 << 14)) {
+        if (n <= 2 * t) throw std::invalid_argument("RanSha: n > 2t");
+        if (verify_senders == 0) verify_senders = 2 * t + 1;
+        if (verify_senders < 2 * t + 1 || verify_senders > n) throw std::invalid_argument("RanSha: 2t+1 <= verify_senders <= n");
+        coeffs = arena_.take(n * K * (t + 1));
+        S = arena_.take(n * n * K), x_ = arena_.take(n * n * K), y_ = arena_.take(n * n * K);
+        poly_ = arena_.take(K * (t + 1));
+        status_ = static_cast<uint8_t*>(arena_.take_bytes(K));
+        summ_ = static_cast<hbmpc_recover_summary*>(arena_.take_bytes(64));
+        bad = static_cast<uint32_t*>(arena_.take_bytes(64));
+        out = arena_.take(n * nout);
+        for (size_t i = 0; i < verify_senders; ++i) ids_.push_back(i);
+    }
+    void deal() { Producer::deal(coeffs, t_, S); }
+    // everything after the dealers' messages have arrived
+    void finish() {
+        const size_t n = n_, t = t_, K = K_;
+        mix(S, x_, y_);
+        clear_bad(bad);
+        for (size_t i = 0; i < 2 * t; ++i) {  // verifier i: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530)
+            pl_check(hbmpc_dev_batch_recover_strided(ctx_, ids_.data(), ids_.size(), y_ + i * n * K, K, K, n, t, t, 0, poly_, nullptr, status_,
+                                                     summ_, stream_), ctx_, "verifier reconstruction");
+            pl_check(hbmpc_dev_check_degree(ctx_, poly_, status_, K, t + 1, t, bad, stream_), ctx_, "degree test");
+        }
+        // rows 2t .. n - 1 of every batch element, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
+        pl_check(hbmpc_dev_transpose(ctx_, y_ + 2 * t * n * K, n - 2 * t, K, n * K, out, n - 2 * t, n, K, nout, stream_), ctx_, "output shares");
+    }
+    void run() override {
+        deal();
+        finish();
+    }
+    const size_t nout;  // output shares per party
+    U256 *coeffs, *S, *out;  // [dealer][K][t + 1]; [dealer][recipient][K]; [party][K][n - 2t]
+    uint32_t* bad;
+
+  private:
+    DeviceArena arena_;
+    U256 *x_, *y_, *poly_;
+    uint8_t* status_;
+    hbmpc_recover_summary* summ_;
+    std::vector<size_t> ids_;
+};
+
+// K batch elements per dealer -> (t + 1) K double sharings per party, verified by parties t + 1 .. n - 1, each of which
+// interpolates both polynomials through ALL n shares (ran_dou_sha/mod.rs:557-602)
+class RanDouSha : public Producer {
+  public:
+    RanDouSha(hbmpc_ctx* ctx, size_t n, size_t t, size_t K, void* stream)
+        : Producer(ctx, n, t, K, stream), nout((t + 1) * K),
+          arena_(ctx, (n * K * (3 * t + 2) + 5 * n * n * K + 2 * K * n + 2 * n * (t + 1) * K) * 32 + 8 * K + (1 << 14)) {
+        coeffs_t = arena_.take(n * K * (t + 1)), coeffs_2t = arena_.take(n * K * (2 * t + 1));
+        S_t = arena_.take(n * n * K), S_2t = arena_.take(n * n * K);
+        x_ = arena_.take(n * n * K), y_t_ = arena_.take(n * n * K), y_2t_ = arena_.take(n * n * K);
+        poly_t_ = arena_.take(K * n), poly_2t_ = arena_.take(K * n);
+        deg_ = static_cast<uint32_t*>(arena_.take_bytes(4 * K));
+        bad = static_cast<uint32_t*>(arena_.take_bytes(64));
+        out_t = arena_.take(n * nout), out_2t = arena_.take(n * nout);
+        for (size_t i = 0; i < n; ++i) ids_.push_back(i);
+    }
+    void deal() {  // DouShaNode::init_batch: both sharings of every secret
+        Producer::deal(coeffs_t, t_, S_t);
+        Producer::deal(coeffs_2t, 2 * t_, S_2t);
+    }
+    void finish() {
+        const size_t n = n_, t = t_, K = K_;
+        mix(S_t, x_, y_t_);    // RanDouShaNode::init_batch step 1
+        mix(S_2t, x_, y_2t_);  // step 2
+        clear_bad(bad);
+        for (size_t i = t + 1; i < n; ++i) {  // step 3: verifier i
+            pl_check(hbmpc_dev_batch_interpolate(ctx_, ids_.data(), n, y_t_ + i * n * K, K, K, n, poly_t_, deg_, stream_), ctx_, "interpolate [r]_t");
+            pl_check(hbmpc_dev_batch_interpolate(ctx_, ids_.data(), n, y_2t_ + i * n * K, K, K, n, poly_2t_, deg_, stream_), ctx_, "interpolate [r]_2t");
+            pl_check(hbmpc_dev_check_double_share(ctx_, poly_t_, poly_2t_, K, n, t, bad, stream_), ctx_, "degree / equal-secret tests");
+        }
+        // steps 4-5: rows 0 .. t, per party in the order [k][i]  (ran_dou_sha/mod.rs:314-331)
+        pl_check(hbmpc_dev_transpose(ctx_, y_t_, t + 1, K, n * K, out_t, t + 1, n, K, nout, stream_), ctx_, "output [r]_t");
+        pl_check(hbmpc_dev_transpose(ctx_, y_2t_, t + 1, K, n * K, out_2t, t + 1, n, K, nout, stream_), ctx_, "output [r]_2t");
+    }
+    void run() override {
+        deal();
+        finish();
+    }
+    const size_t nout;
+    U256 *coeffs_t, *coeffs_2t, *S_t, *S_2t, *out_t, *out_2t;
+    uint32_t* bad;
+
+  private:
+    DeviceArena arena_;
+    U256 *x_, *y_t_, *y_2t_, *poly_t_, *poly_2t_;
+    uint32_t* deg_;
+    std::vector<size_t> ids_;
+};
+
+// run_preprocessing's triple part for all n parties, device-resident from the dealers' polynomials to [c]_t: RanSha produces
+// 2 N random sharings per party (a = the first N, b = the next N: take_random_shares twice, honeybadger/mod.rs:1307-1316),
+// RanDouSha the N double sharings, TripleGen consumes them where they lie.
+class Preprocessing {
+  public:
+    Preprocessing(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, void* stream)
+        : rs(ctx, n, t, (2 * N + (n - 2 * t) - 1) / (n - 2 * t), stream), rd(ctx, n, t, (N + t) / (t + 1), stream), tg(ctx, n, t, N, stream),
+          ctx_(ctx), stream_(stream), n_(n), N_(N) {}
+    void run() {
+        rs.run();
+        rd.run();
+        for (size_t p = 0; p < n_; ++p) {  // the parties' lists, in the reference's order, become TripleGen's [party][N] inputs
+            copy(tg.a + p * N_, rs.out + p * rs.nout);
+            copy(tg.b + p * N_, rs.out + p * rs.nout + N_);
+            copy(tg.rt + p * N_, rd.out_t + p * rd.nout);
+            copy(tg.r2t + p * N_, rd.out_2t + p * rd.nout);
+        }
+        tg.run();
+    }
+    RanSha rs;
+    RanDouSha rd;
+    TripleGen tg;
+
+  private:
+    void copy(U256* dst, const U256* src) { pl_check(hbmpc_memcpy_d2d(ctx_, dst, src, N_ * sizeof(U256), stream_), ctx_, "d2d"); }
+    hbmpc_ctx* ctx_;
+    void* stream_;
+    size_t n_, N_;
 };
 
 }  // namespace hbmpc

@@ -1542,4 +1542,41 @@ extern "C" ShareErrorCode hbmpc_dev_validate_canonical(hbmpc_ctx* ctx, const U25
     return ShareSuccess;
 }
 
+// ---- layout / verdict steps of the preprocessing producers (either field: the element size follows the context) ----
+extern "C" ShareErrorCode hbmpc_dev_transpose(hbmpc_ctx* ctx, const void* src_dev, size_t rows, size_t cols, size_t src_row_stride,
+                                              void* dst_dev, size_t dst_row_stride, size_t batch, size_t src_batch_stride,
+                                              size_t dst_batch_stride, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (rows == 0 || cols == 0 || batch == 0) return ShareSuccess;
+    if (!src_dev || !dst_dev) return fail(ctx, InvalidInput, "null buffer");
+    if (src_row_stride < cols || dst_row_stride < rows) return fail(ctx, InvalidInput, "row stride below the row length");
+    if (batch > 65535 || (rows + 15) / 16 > 65535) return fail(ctx, InvalidInput, "batch / rows beyond the launch grid");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    launch_transpose(is_gold(ctx) ? 1 : 4, (const uint64_t*)src_dev, rows, cols, src_row_stride, (uint64_t*)dst_dev, dst_row_stride, batch,
+                     src_batch_stride, dst_batch_stride, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_check_degree(hbmpc_ctx* ctx, const void* coeffs_dev, const uint8_t* status_dev, size_t G, size_t m,
+                                                 size_t want_degree, uint32_t* bad_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!bad_dev || (G && !coeffs_dev) || m == 0 || m > 65535) return fail(ctx, InvalidInput, "null buffer or bad length");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (G) launch_check_degree(is_gold(ctx) ? 1 : 4, (const uint64_t*)coeffs_dev, status_dev, G, (int)m, (int)want_degree, bad_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const void* coeffs_t_dev, const void* coeffs_2t_dev, size_t G, size_t m,
+                                                       size_t t, uint32_t* bad_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!bad_dev || (G && (!coeffs_t_dev || !coeffs_2t_dev)) || m == 0 || m > 65535) return fail(ctx, InvalidInput, "null buffer or bad length");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (G) launch_check_double(is_gold(ctx) ? 1 : 4, (const uint64_t*)coeffs_t_dev, (const uint64_t*)coeffs_2t_dev, G, (int)m, (int)t, bad_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+
 #include "capi_recover.inc"

@@ -152,4 +152,78 @@ __global__ __launch_bounds__(256) void k_poly_degree(const uint64_t* __restrict_
     degree_out[g] = (uint32_t)deg;
 }
 
+
+// ---- layout and verdict kernels of the preprocessing producers (RanSha / RanDouSha) --------------------------------
+// dst[b][c][r] = src[b][r][c] for elements of W 64-bit words: the dealers' outputs S[dealer][recipient, k] become the
+// recipients' inputs x[recipient, k][dealer] of the n x n Vandermonde (share_gen.rs:401-418, ran_dou_sha/mod.rs:392-403),
+// and the selected output rows y[i][party, k] become each party's list [k][i] in the reference's order
+// (share_gen.rs:199-203, ran_dou_sha/mod.rs:314-331).  A 16 x 64 tile goes through LDS so that both sides move whole
+// runs of elements.
+template <int W>
+struct LayoutElem {
+    uint64_t w[W];
+};
+template <int W>
+__global__ __launch_bounds__(256) void k_transpose(const uint64_t* __restrict__ src, size_t rows, size_t cols, size_t src_row_stride,
+                                                   uint64_t* __restrict__ dst, size_t dst_row_stride, size_t src_batch_stride,
+                                                   size_t dst_batch_stride) {
+    constexpr int TR = 16, TC = 64;
+    __shared__ LayoutElem<W> tile[TR][TC + 1];
+    const LayoutElem<W>* s = reinterpret_cast<const LayoutElem<W>*>(src) + (size_t)blockIdx.z * src_batch_stride;
+    LayoutElem<W>* d = reinterpret_cast<LayoutElem<W>*>(dst) + (size_t)blockIdx.z * dst_batch_stride;
+    const size_t r0 = (size_t)blockIdx.y * TR, c0 = (size_t)blockIdx.x * TC;
+    for (int k = threadIdx.x; k < TR * TC; k += 256) {
+        const int r = k / TC, c = k % TC;
+        if (r0 + r < rows && c0 + c < cols) tile[r][c] = s[(r0 + r) * src_row_stride + c0 + c];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < TR * TC; k += 256) {
+        const int c = k / TR, r = k % TR;
+        if (r0 + r < rows && c0 + c < cols) d[(c0 + c) * dst_row_stride + r0 + r] = tile[r][c];
+    }
+}
+// degree (DensePolynomial::degree(): 0 for the zero polynomial) of polynomial g, coefficients at coeffs + g * stride
+template <int W>
+__device__ inline int layout_degree(const uint64_t* coeffs, int m) {
+    for (int k = m - 1; k > 0; --k) {
+        uint64_t any = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) any |= coeffs[(size_t)k * W + w];
+        if (any != 0) return k;
+    }
+    return 0;
+}
+// RanSha verifier (share_gen.rs:516-530): counts the chunks whose reconstruction failed (status not 0 / 1) or whose
+// polynomial does not have degree exactly `want`.  bad[0] += count, bad[1] = min(first bad chunk).
+template <int W>
+__global__ __launch_bounds__(256) void k_check_degree(const uint64_t* __restrict__ coeffs, const uint8_t* __restrict__ status, size_t G, int m,
+                                                      int want, uint32_t* __restrict__ bad) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool wrong = false;
+    if (g < G) wrong = (status && status[g] > 1) || layout_degree<W>(coeffs + g * (size_t)m * W, m) != want;
+    const unsigned long long mask = __ballot(wrong);
+    if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
+        atomicAdd(bad, (uint32_t)__popcll(mask));
+        atomicMin(bad + 1, (uint32_t)g);
+    }
+}
+// RanDouSha verifier (ran_dou_sha/mod.rs:586-589): degree(poly_t) == t, degree(poly_2t) == 2 t and equal constant terms
+template <int W>
+__global__ __launch_bounds__(256) void k_check_double(const uint64_t* __restrict__ ct, const uint64_t* __restrict__ c2t, size_t G, int m, int t,
+                                                      uint32_t* __restrict__ bad) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool wrong = false;
+    if (g < G) {
+        const uint64_t *a = ct + g * (size_t)m * W, *b = c2t + g * (size_t)m * W;
+        wrong = layout_degree<W>(a, m) != t || layout_degree<W>(b, m) != 2 * t;
+#pragma unroll
+        for (int w = 0; w < W; ++w) wrong |= a[w] != b[w];
+    }
+    const unsigned long long mask = __ballot(wrong);
+    if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
+        atomicAdd(bad, (uint32_t)__popcll(mask));
+        atomicMin(bad + 1, (uint32_t)g);
+    }
+}
+
 }  // namespace hbmpc

@@ -103,5 +103,10 @@ void launch_unpack_shares(const uint64_t* payload, size_t N, uint64_t id, uint64
                           uint32_t* status, hipStream_t s);
 void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hipStream_t s);
 void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s);
+// layout + verdict kernels of the preprocessing producers (kernels_codec.hpp); ew64 = 64-bit words per element
+void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, size_t src_row_stride, uint64_t* dst, size_t dst_row_stride,
+                      size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s);
+void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status, size_t G, int m, int want, uint32_t* bad, hipStream_t s);
+void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s);
 
 }  // namespace hbmpc

@@ -37,4 +37,20 @@ void launch_validate_fvec(const uint64_t* payloads, size_t payload_stride_words,
     if (gold) hipLaunchKernelGGL(k_validate_fvec_gl, grid, dim3(256), 0, s, payloads, payload_stride_words, G, status);
     else hipLaunchKernelGGL(k_validate_fvec, grid, dim3(256), 0, s, payloads, payload_stride_words, G, status);
 }
+void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, size_t src_row_stride, uint64_t* dst, size_t dst_row_stride,
+                      size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s) {
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 15) / 16), (unsigned)batch);
+    if (ew64 == 4) hipLaunchKernelGGL(k_transpose<4>, grid, dim3(256), 0, s, src, rows, cols, src_row_stride, dst, dst_row_stride, src_batch_stride, dst_batch_stride);
+    else hipLaunchKernelGGL(k_transpose<1>, grid, dim3(256), 0, s, src, rows, cols, src_row_stride, dst, dst_row_stride, src_batch_stride, dst_batch_stride);
+}
+void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status, size_t G, int m, int want, uint32_t* bad, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_degree<4>, grid, dim3(256), 0, s, coeffs, status, G, m, want, bad);
+    else hipLaunchKernelGGL(k_check_degree<1>, grid, dim3(256), 0, s, coeffs, status, G, m, want, bad);
+}
+void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_double<4>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
+    else hipLaunchKernelGGL(k_check_double<1>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
+}
 }

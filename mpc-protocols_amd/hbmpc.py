@@ -386,6 +386,26 @@ class Engine:
                                                     C.c_uint64(first_index), C.c_size_t(n), C.c_size_t(d),
                                                     C.c_void_p(coeffs_ws_d), C.c_void_p(out_d), C.c_void_p(stream))
 
+    def dev_batch_interpolate(self, ids, evals_d, row_stride, G, n, coeffs_d, degree_d, stream=0):
+        """plain Lagrange through ALL len(ids) sender rows (row s at evals_d + s * row_stride elements): coeffs[G][S], degree[G]"""
+        return self._f("dev_batch_interpolate")(self.ctx, _p(_sz(ids)), C.c_size_t(len(ids)), C.c_void_p(evals_d), C.c_size_t(row_stride),
+                                                C.c_size_t(G), C.c_size_t(n), C.c_void_p(coeffs_d), C.c_void_p(degree_d), C.c_void_p(stream))
+
+    def dev_transpose(self, src_d, rows, cols, src_row_stride, dst_d, dst_row_stride, batch=1, src_batch_stride=0, dst_batch_stride=0,
+                      stream=0):
+        """dst[b][c][r] = src[b][r][c]; strides in elements of this engine's field"""
+        return self.L.hbmpc_dev_transpose(self.ctx, C.c_void_p(src_d), C.c_size_t(rows), C.c_size_t(cols), C.c_size_t(src_row_stride),
+                                          C.c_void_p(dst_d), C.c_size_t(dst_row_stride), C.c_size_t(batch), C.c_size_t(src_batch_stride),
+                                          C.c_size_t(dst_batch_stride), C.c_void_p(stream))
+
+    def dev_check_degree(self, coeffs_d, status_d, G, m, want_degree, bad_d, stream=0):
+        return self.L.hbmpc_dev_check_degree(self.ctx, C.c_void_p(coeffs_d), C.c_void_p(status_d), C.c_size_t(G), C.c_size_t(m),
+                                             C.c_size_t(want_degree), C.c_void_p(bad_d), C.c_void_p(stream))
+
+    def dev_check_double_share(self, ct_d, c2t_d, G, m, t, bad_d, stream=0):
+        return self.L.hbmpc_dev_check_double_share(self.ctx, C.c_void_p(ct_d), C.c_void_p(c2t_d), C.c_size_t(G), C.c_size_t(m),
+                                                   C.c_size_t(t), C.c_void_p(bad_d), C.c_void_p(stream))
+
     def dev_vandermonde_apply(self, x_d, G, n, d, y_d, stream=0):
         return self._f("dev_vandermonde_apply")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n),
                                                   C.c_size_t(d), C.c_void_p(y_d), C.c_void_p(stream))

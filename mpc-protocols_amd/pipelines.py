@@ -7,6 +7,11 @@ layout choice (strided sender rows), nothing is copied between "parties".
                triple_gen/triple_generation.rs:304-364,164-232; batch_recon/batch_recon.rs:144-185,332-481
   fpmul        FPMulNode::init = Multiply (Beaver, RBC path) + TruncPrNode
                fpmul/fpmul.rs:61-110, mul/multiplication.rs:417-426,57-139, fpmul/truncpr.rs:185-318
+  ransha       RanShaNode::init_batch + init_ransha_batch + reconstruction_handler + try_finalize: the random degree-t
+               sharings triple_gen consumes as a, b            share_gen/share_gen.rs:232-289,401-454,516-530,199-203
+  randousha    DouShaNode::init_batch + RanDouShaNode::init_batch + reconstruction_handler + try_finalize: the double
+               sharings ([r]_t, [r]_2t)     double_share/double_share_generation.rs:151-215, ran_dou_sha/mod.rs:371-449,569-602,314-331
+  preprocessing  run_preprocessing's triple part (honeybadger/mod.rs:1239-1393): ransha -> a, b; randousha -> r; triple_gen
 """
 from __future__ import annotations
 
@@ -198,3 +203,203 @@ class FpMul(_Capturable):
     def close(self):
         self._drop_graph()
         self.arena.free()
+
+
+class _Producer(_Capturable):
+    """What RanSha and RanDouSha share: every dealer p deals K secrets to the n recipients (the dealers' polynomials are
+    the INPUT: coefficient rows [dealer][K][deg + 1], column 0 the secret -- filled by the host, or on the device by
+    hbmpc_dev_fill_coeffs: the reference draws them from each party's rng), recipient j multiplies the vector of the n
+    shares it received for batch element k by the n x n Vandermonde matrix make_vandermonde(n, n - 1), row i of the
+    result goes to verifier i, and the other rows are the party's output.
+
+    Layouts (elements; all n parties on one device):  dealt S[p][j, k]  --transpose-->  x[j, k][p]  --Vandermonde-->
+    y[i][j, k]; what party j sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied."""
+
+    def __init__(self, eng, n, t, K, stream=0):
+        self.eng, self.n, self.t, self.K, self.stream = eng, n, t, K, stream
+        self.U = 32 if eng.field == "fr" else 8
+
+    def _deal(self, coeffs, deg, S):
+        """coeffs [n dealers][K][deg + 1] -> S[dealer][recipient][K]: every dealer's compute_shares"""
+        e, n, K, s, U = self.eng, self.n, self.K, self.stream, self.U
+        for p in range(n):  # dealer p: RobustShare / NonRobustShare::compute_shares for each of its K secrets
+            _check(e.dev_compute_shares(coeffs + p * K * (deg + 1) * U, K, n, deg, S + p * n * K * U, s), e, "deal")
+
+    def _mix(self, S, x, y):
+        """y[i][j, k] = sum_p alpha_i^p * S[p][j, k]: what every recipient computes from the n shares it was dealt"""
+        e, n, K, s = self.eng, self.n, self.K, self.stream
+        _check(e.dev_transpose(S, n, n * K, n * K, x, n, stream=s), e, "dealt shares -> recipients")
+        _check(e.dev_vandermonde_apply(x, n * K, n, n - 1, y, s), e, "n x n Vandermonde")
+
+    def _bad(self):
+        b = np.zeros(2, dtype=np.uint32)
+        self.eng.d2h(b, self.bad, self.stream)
+        self.eng.sync(self.stream)
+        return int(b[0]), int(b[1])
+
+    def _clear_bad(self):
+        self.eng.h2d(self.bad, np.array([0, 0xFFFFFFFF], dtype=np.uint32), self.stream)
+
+
+class RanSha(_Producer):
+    """K batch elements per dealer -> (n - 2t) K random degree-t sharings per party, verified by parties 0 .. 2t - 1.
+    verify_senders: how many parties' shares a verifier reconstructs from.  Default 2t + 1: the reference's handler fires
+    as soon as that many have arrived (share_gen.rs:497: `received_r_shares.len() >= 2 * self.threshold + 1`), i.e. the
+    first 2t + 1 senders -- with degree t that is a decode with no OEC round."""
+
+    def __init__(self, eng, n, t, K, stream=0, verify_senders=None):
+        super().__init__(eng, n, t, K, stream)
+        self.verify_senders = 2 * t + 1 if verify_senders is None else verify_senders
+        assert 2 * t + 1 <= self.verify_senders <= n and n > 2 * t
+        U = self.U
+        self.nout = (n - 2 * t) * K                      # output shares per party
+        self.arena = DeviceArena(eng, (n * K * (t + 1) + 3 * n * n * K + K * (t + 1) + n * self.nout) * U + K + (1 << 14))
+        ar = self.arena
+        self.coeffs = ar.take(n * K * (t + 1) * U)       # [dealer][K][t + 1]
+        self.S = ar.take(n * n * K * U)                  # [dealer][recipient][K]
+        self.x = ar.take(n * n * K * U)                  # [recipient][K][dealer]
+        self.y = ar.take(n * n * K * U)                  # [row i][party][K]
+        self.poly = ar.take(K * (t + 1) * U)
+        self.status = ar.take(K)
+        self.summ = ar.take(64)
+        self.bad = ar.take(64)
+        self.out = ar.take(n * self.nout * U)            # [party][K][n - 2t]: the reference's output order (share_gen.rs:199-203)
+
+    def upload(self, coeffs):
+        self.eng.h2d(self.coeffs, np.ascontiguousarray(coeffs), self.stream)
+
+    def deal(self):
+        self._deal(self.coeffs, self.t, self.S)
+
+    def run(self, check=True):
+        self.deal()
+        self.finish(check)
+
+    def finish(self, check=True):
+        """everything after the dealers' messages have arrived (tests corrupt S in between)"""
+        e, n, t, K, s, U = self.eng, self.n, self.t, self.K, self.stream, self.U
+        self._mix(self.S, self.x, self.y)
+        # verifier i < 2t: recover_secret of the K columns from the first verify_senders parties' shares, then the exact-degree
+        # test (share_gen.rs:516-530); the verdicts stay on the device (bad[0] = chunks that failed, bad[1] = the first)
+        self._clear_bad()
+        ids = list(range(self.verify_senders))
+        for i in range(2 * t):
+            _check(e.dev_batch_recover_strided(ids, self.y + i * n * K * U, K, K, n, t, t, self.poly, status_d=self.status,
+                                               summary_d=self.summ, stream=s), e, "verifier reconstruction")
+            _check(e.dev_check_degree(self.poly, self.status, K, t + 1, t, self.bad, s), e, "degree test")
+        # output: rows 2t .. n - 1 of every batch element, per party in the order [k][i - 2t]
+        _check(e.dev_transpose(self.y + 2 * t * n * K * U, n - 2 * t, K, n * K, self.out, n - 2 * t, batch=n, src_batch_stride=K,
+                               dst_batch_stride=self.nout, stream=s), e, "output shares")
+        if check:
+            bad, first = self._bad()
+            if bad:
+                raise RuntimeError(f"RanSha: {bad} verifier reconstructions failed or had the wrong degree (first: column {first})")
+
+    def download(self):
+        out = self.eng._new((self.n, self.nout))
+        self.eng.d2h(out, self.out, self.stream)
+        self.eng.sync(self.stream)
+        return out
+
+    def close(self):
+        self._drop_graph()
+        self.arena.free()
+
+
+class RanDouSha(_Producer):
+    """K batch elements per dealer -> (t + 1) K double sharings ([r]_t, [r]_2t) per party, verified by parties t + 1 .. n - 1
+    (each reconstructs both polynomials through ALL n shares: ran_dou_sha/mod.rs:557-559 waits for 2t + 1 degree-t and n
+    degree-2t shares, and in one process all n of both have arrived)."""
+
+    def __init__(self, eng, n, t, K, stream=0):
+        super().__init__(eng, n, t, K, stream)
+        U = self.U
+        self.nout = (t + 1) * K
+        self.arena = DeviceArena(eng, (n * K * (3 * t + 2) + 5 * n * n * K + 2 * K * n + 2 * n * self.nout) * U + 8 * K + (1 << 14))
+        ar = self.arena
+        self.coeffs_t = ar.take(n * K * (t + 1) * U)     # [dealer][K][t + 1]
+        self.coeffs_2t = ar.take(n * K * (2 * t + 1) * U)  # [dealer][K][2t + 1]   (same secrets in column 0)
+        self.S_t = ar.take(n * n * K * U)
+        self.S_2t = ar.take(n * n * K * U)
+        self.x = ar.take(n * n * K * U)
+        self.y_t = ar.take(n * n * K * U)
+        self.y_2t = ar.take(n * n * K * U)
+        self.poly_t = ar.take(K * n * U)
+        self.poly_2t = ar.take(K * n * U)
+        self.deg = ar.take(4 * K)
+        self.bad = ar.take(64)
+        self.out_t = ar.take(n * self.nout * U)          # [party][K][t + 1]  (ran_dou_sha/mod.rs:314-331)
+        self.out_2t = ar.take(n * self.nout * U)
+
+    def upload(self, coeffs_t, coeffs_2t):
+        self.eng.h2d(self.coeffs_t, np.ascontiguousarray(coeffs_t), self.stream)
+        self.eng.h2d(self.coeffs_2t, np.ascontiguousarray(coeffs_2t), self.stream)
+
+    def deal(self):
+        self._deal(self.coeffs_t, self.t, self.S_t)           # DouShaNode::init_batch: both sharings of every secret
+        self._deal(self.coeffs_2t, 2 * self.t, self.S_2t)
+
+    def run(self, check=True):
+        self.deal()
+        self.finish(check)
+
+    def finish(self, check=True):
+        e, n, t, K, s, U = self.eng, self.n, self.t, self.K, self.stream, self.U
+        self._mix(self.S_t, self.x, self.y_t)                 # RanDouShaNode::init_batch step 1
+        self._mix(self.S_2t, self.x, self.y_2t)               # step 2
+        self._clear_bad()
+        ids = list(range(n))
+        for i in range(t + 1, n):                                              # step 3: verifier i
+            _check(e.dev_batch_interpolate(ids, self.y_t + i * n * K * U, K, K, n, self.poly_t, self.deg, s), e, "interpolate [r]_t")
+            _check(e.dev_batch_interpolate(ids, self.y_2t + i * n * K * U, K, K, n, self.poly_2t, self.deg, s), e, "interpolate [r]_2t")
+            _check(e.dev_check_double_share(self.poly_t, self.poly_2t, K, n, t, self.bad, s), e, "degree / equal-secret tests")
+        for y, out in ((self.y_t, self.out_t), (self.y_2t, self.out_2t)):      # steps 4-5: rows 0 .. t
+            _check(e.dev_transpose(y, t + 1, K, n * K, out, t + 1, batch=n, src_batch_stride=K, dst_batch_stride=self.nout, stream=s), e,
+                   "output double shares")
+        if check:
+            bad, first = self._bad()
+            if bad:
+                raise RuntimeError(f"RanDouSha: {bad} verifier checks failed (first: column {first})")
+
+    def download(self):
+        a, b = self.eng._new((self.n, self.nout)), self.eng._new((self.n, self.nout))
+        self.eng.d2h(a, self.out_t, self.stream)
+        self.eng.d2h(b, self.out_2t, self.stream)
+        self.eng.sync(self.stream)
+        return a, b
+
+    def close(self):
+        self._drop_graph()
+        self.arena.free()
+
+
+class Preprocessing:
+    """run_preprocessing's triple part (honeybadger/mod.rs:1239-1393) for all n parties, device-resident from the dealers'
+    polynomials to [c]_t: RanSha produces 2 N random sharings per party (a = the first N, b = the next N:
+    take_random_shares twice, :1307-1316), RanDouSha the N double sharings, TripleGen consumes them where they lie."""
+
+    def __init__(self, eng, n, t, N, stream=0):
+        assert N % (2 * t + 1) == 0
+        self.eng, self.n, self.t, self.N, self.stream = eng, n, t, N, stream
+        self.K_rs = -(-2 * N // (n - 2 * t))             # RanSha batch elements per dealer: (n - 2t) K >= 2 N
+        self.K_rd = -(-N // (t + 1))                     # RanDouSha: (t + 1) K >= N
+        self.rs = RanSha(eng, n, t, self.K_rs, stream)
+        self.rd = RanDouSha(eng, n, t, self.K_rd, stream)
+        self.tg = TripleGen(eng, n, t, N, stream)
+
+    def run(self, check=True):
+        e, n, N, s = self.eng, self.n, self.N, self.stream
+        U = self.rs.U
+        self.rs.run(check)
+        self.rd.run(check)
+        for p in range(n):   # the parties' lists, in the reference's order, become TripleGen's [party][N] inputs
+            e.d2d(self.tg.a + p * N * U, self.rs.out + p * self.rs.nout * U, N * U, s)
+            e.d2d(self.tg.b + p * N * U, self.rs.out + (p * self.rs.nout + N) * U, N * U, s)
+            e.d2d(self.tg.rt + p * N * U, self.rd.out_t + p * self.rd.nout * U, N * U, s)
+            e.d2d(self.tg.r2t + p * N * U, self.rd.out_2t + p * self.rd.nout * U, N * U, s)
+        self.tg.run(check)
+
+    def close(self):
+        self.rs.close()
+        self.rd.close()
+        self.tg.close()

@@ -509,6 +509,72 @@ def nonrobust_recover_secret(shares, n: int):
 
 
 # ---------------------------------------------------------------------------------------------
+# Preprocessing producers: RanSha (share_gen/share_gen.rs), DouSha (double_share/double_share_generation.rs),
+# RanDouSha (ran_dou_sha/mod.rs) -- the arithmetic of all n parties, messages replaced by lists.
+# The dealers' polynomials are inputs (the reference draws them from each party's rng): coeffs[p][k] = coefficient list
+# of dealer p's k-th polynomial, coeffs[p][k][0] the secret.
+# ---------------------------------------------------------------------------------------------
+def _deal_and_mix(coeffs, n: int, deg: int):
+    """-> r[j][k] = the n shares [r_0 .. r_{n-1}] party j holds for batch element k: every dealer's compute_shares
+    (share_gen.rs:251-259 / double_share_generation.rs:168-181), sorted by dealer id (:375-384), then
+    apply_vandermonde(make_vandermonde(n, n - 1), .) per batch element (:415-419 / ran_dou_sha/mod.rs:392-403)."""
+    K = len(coeffs[0])
+    dealt = [[compute_shares(coeffs[p][k], n, deg) for k in range(K)] for p in range(n)]   # dealt[p][k][j]
+    vdm = make_vandermonde(n, n - 1)
+    return [[apply_vandermonde(vdm, [dealt[p][k][j] for p in range(n)]) for k in range(K)] for j in range(n)]
+
+
+def ransha(coeffs, n: int, t: int, verify_senders=None):
+    """-> (outputs, ok): outputs[j] = party j's (n - 2t) K random sharings in the reference's order (try_finalize,
+    share_gen.rs:199-203); ok[i] = verifier i's verdict, i < 2t: recover_secret of every batch element from the shares of
+    the first `verify_senders` parties (the handler fires at 2t + 1 received, :497) and the exact-degree test (:516-530)."""
+    verify_senders = 2 * t + 1 if verify_senders is None else verify_senders
+    K = len(coeffs[0])
+    r = _deal_and_mix(coeffs, n, t)
+    ok = []
+    for i in range(2 * t):
+        good = True
+        for k in range(K):
+            shares = [r[j][k][i] for j in range(verify_senders)]
+            try:
+                poly, _ = recover_secret([Share(sh.v, j, t) for j, sh in enumerate(shares)], n, t)
+                if p_degree(poly) != t:
+                    good = False
+            except ShareErr:
+                good = False
+            if not good:
+                break
+        ok.append(good)
+    outputs = [[sh.v for k in range(K) for sh in r[j][k][2 * t:]] for j in range(n)]
+    return outputs, ok
+
+
+def randousha(coeffs_t, coeffs_2t, n: int, t: int):
+    """-> (out_t, out_2t, ok): party j's (t + 1) K double sharings (try_finalize, ran_dou_sha/mod.rs:314-331) and the
+    verdicts of verifiers t + 1 .. n - 1: NonRobustShare::recover_secret of both polynomials through all n shares, exact
+    degrees t and 2t, equal secrets (:569-602)."""
+    K = len(coeffs_t[0])
+    rt, r2t = _deal_and_mix(coeffs_t, n, t), _deal_and_mix(coeffs_2t, n, 2 * t)
+    ok = []
+    for i in range(t + 1, n):
+        good = True
+        for k in range(K):
+            try:
+                p1, s1 = nonrobust_recover_secret([Share(rt[j][k][i].v, j, t) for j in range(n)], n)
+                p2, s2 = nonrobust_recover_secret([Share(r2t[j][k][i].v, j, 2 * t) for j in range(n)], n)
+                if p_degree(p1) != t or p_degree(p2) != 2 * t or s1 != s2:
+                    good = False
+            except ShareErr:
+                good = False
+            if not good:
+                break
+        ok.append(good)
+    out_t = [[sh.v for k in range(K) for sh in rt[j][k][: t + 1]] for j in range(n)]
+    out_2t = [[sh.v for k in range(K) for sh in r2t[j][k][: t + 1]] for j in range(n)]
+    return out_t, out_2t, ok
+
+
+# ---------------------------------------------------------------------------------------------
 # a11  triple_gen local math  (triple_gen/triple_generation.rs:333-340, 196-208)
 # ---------------------------------------------------------------------------------------------
 def triple_local(a: Share, b: Share, r2t: Share) -> Share:

@@ -119,6 +119,42 @@ static void fpmul(void* stream) {
     CHECK(same(out, out2));
 }
 
+// dealers' polynomials -> RanSha / DouSha + RanDouSha -> TripleGen, all on the device; the opened c must equal a * b
+// for the secrets the producers' outputs open to, and tampering with one dealt share must turn the verdict
+static void preprocessing(void* stream) {
+    const size_t n = 7, t = 2, groups = 4, N = groups * (2 * t + 1);
+    Preprocessing pre(context(), n, t, N, stream);
+    const size_t Krs = pre.rs.nout / (n - 2 * t), Krd = pre.rd.nout / (t + 1);
+    std::vector<U256> co(n * Krs * (t + 1)), ct(n * Krd * (t + 1)), c2t(n * Krd * (2 * t + 1));
+    for (auto& v : co) v = rand_fr();
+    for (auto& v : ct) v = rand_fr();
+    for (auto& v : c2t) v = rand_fr();
+    for (size_t pk = 0; pk < n * Krd; ++pk) c2t[pk * (2 * t + 1)] = ct[pk * (t + 1)];  // the same secret in both sharings
+    pre.rs.upload(pre.rs.coeffs, co.data(), co.size());
+    pre.rd.upload(pre.rd.coeffs_t, ct.data(), ct.size());
+    pre.rd.upload(pre.rd.coeffs_2t, c2t.data(), c2t.size());
+    pre.run();
+    uint32_t v1[2], v2[2];
+    pre.rs.verdict(pre.rs.bad, v1);
+    pre.rd.verdict(pre.rd.bad, v2);
+    CHECK(v1[0] == 0 && v2[0] == 0);
+    CHECK(pre.tg.last_summary(pre.tg.summ).n_failed == 0);
+    std::vector<U256> a(n * N), b(n * N), c(n * N);
+    pre.tg.download(a.data(), pre.tg.a, n * N);
+    pre.tg.download(b.data(), pre.tg.b, n * N);
+    pre.tg.download(c.data(), pre.tg.c, n * N);
+    CHECK(same(open_all(c, n, N, t, t), mul_all(open_all(a, n, N, t, t), open_all(b, n, N, t, t))));
+    // one dealt share changed before the recipients mix: the verifiers must notice
+    pre.rs.deal();
+    std::vector<U256> one(1);
+    pre.rs.download(one.data(), pre.rs.S + (3 * n + 1) * Krs + 2, 1);
+    one[0].data[0] ^= 1;
+    pre.rs.upload(pre.rs.S + (3 * n + 1) * Krs + 2, one.data(), 1);
+    pre.rs.finish();
+    pre.rs.verdict(pre.rs.bad, v1);
+    CHECK(v1[0] >= 1 && v1[1] == 2);
+}
+
 int main() {
     void* stream = nullptr;
     pl_check(hbmpc_stream_create(context(), &stream), context(), "stream_create");
@@ -126,6 +162,8 @@ int main() {
     triple_gen(stream);
     std::printf("fpmul\n");
     fpmul(stream);
+    std::printf("preprocessing (RanSha, RanDouSha, TripleGen)\n");
+    preprocessing(stream);
     pl_check(hbmpc_stream_destroy(context(), stream), context(), "stream_destroy");
     std::printf(g_failed ? "%d CHECKS FAILED\n" : "pipelines passed (%d failures)\n", g_failed);
     return g_failed ? 1 : 0;

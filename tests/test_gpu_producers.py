@@ -1,0 +1,141 @@
+"""The producer side of config 4 (Missing 1): RanSha, DouSha + RanDouSha as device-resident pipelines of all
+n parties (mpc-protocols_amd/pipelines.py) against the oracle's restatement of share_gen/share_gen.rs,
+double_share/double_share_generation.rs and ran_dou_sha/mod.rs (oracle/spec.py: ransha, randousha) on the same dealers'
+polynomials -- every party's output shares bit for bit, in the reference's order, and the verifiers' verdicts; then the
+whole chain dealers -> [c]_t (run_preprocessing's triple part, honeybadger/mod.rs:1239-1393)."""
+import random
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import spec as SFR
+from oracle.cref import ints_to_u256, u256_to_ints
+from oracle.spec_gl import S as SGL
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(field):
+    if field == "fr":
+        return SFR, (lambda v: ints_to_u256(v)), (lambda a: [u256_to_ints(r) for r in a])
+    return SGL, (lambda v: np.array(v, dtype=np.uint64)), (lambda a: [[int(x) for x in r] for r in a])
+
+
+def _coeffs(S, rng, n, K, deg, secrets=None):
+    return [[[secrets[p][k] if secrets else rng.randrange(S.R_MOD)] + [rng.randrange(S.R_MOD) for _ in range(deg)] for k in range(K)]
+            for p in range(n)]
+
+
+@pytest.mark.parametrize("field", ["fr", "goldilocks"])
+@pytest.mark.parametrize("n,t,K", [(4, 1, 5), (7, 2, 33), (16, 5, 7)])
+def test_ransha_matches_the_oracle(field, n, t, K):
+    S, to_dev, to_int = _field(field)
+    pkg = load_package()
+    eng = pkg.Engine(0, field="fr" if field == "fr" else "goldilocks")
+    rng = random.Random(n * 100 + K)
+    co = _coeffs(S, rng, n, K, t)
+    want, ok = S.ransha(co, n, t)
+    rs = pkg.pipelines.RanSha(eng, n, t, K)
+    try:
+        rs.upload(to_dev([c for row in co for poly in row for c in poly]))
+        rs.run(check=True)
+        assert all(ok) and to_int(rs.download()) == want
+        # all n senders to the verifiers (OEC rounds available): same outputs, same verdict
+        rs2 = pkg.pipelines.RanSha(eng, n, t, K, verify_senders=n)
+        rs2.upload(to_dev([c for row in co for poly in row for c in poly]))
+        rs2.run(check=True)
+        assert to_int(rs2.download()) == want
+        rs2.close()
+        # a dealer sends ONE recipient a wrong share for one batch element: the mixed sharings are no longer of degree t
+        # (share_gen.rs:516-530 -> Output(false)); the oracle restatement says the same about the same tampered inputs
+        rs.deal()
+        k_bad, p_bad, j_bad = K // 2, n - 1, 0
+        U = rs.U
+        one = to_dev([1])
+        cur = eng._new((1,))
+        off = ((p_bad * n + j_bad) * K + k_bad) * U
+        eng.d2h(cur, rs.S + off)
+        eng.sync()
+        v = (int(to_int([cur])[0][0]) + 1) % S.R_MOD
+        eng.h2d(rs.S + off, to_dev([v]))
+        with pytest.raises(RuntimeError, match="RanSha"):
+            rs.finish(check=True)
+        bad, first = rs._bad()
+        assert bad >= 1 and first == k_bad
+        del one
+    finally:
+        rs.close()
+        eng.close()
+
+
+@pytest.mark.parametrize("field", ["fr", "goldilocks"])
+@pytest.mark.parametrize("n,t,K", [(4, 1, 5), (7, 2, 33), (16, 5, 7)])
+def test_randousha_matches_the_oracle(field, n, t, K):
+    S, to_dev, to_int = _field(field)
+    pkg = load_package()
+    eng = pkg.Engine(0, field="fr" if field == "fr" else "goldilocks")
+    rng = random.Random(n * 1000 + K)
+    ct = _coeffs(S, rng, n, K, t)
+    c2t = _coeffs(S, rng, n, K, 2 * t, secrets=[[ct[p][k][0] for k in range(K)] for p in range(n)])
+    want_t, want_2t, ok = S.randousha(ct, c2t, n, t)
+    rd = pkg.pipelines.RanDouSha(eng, n, t, K)
+    try:
+        rd.upload(to_dev([c for row in ct for poly in row for c in poly]), to_dev([c for row in c2t for poly in row for c in poly]))
+        rd.run(check=True)
+        a, b = rd.download()
+        assert all(ok) and to_int(a) == want_t and to_int(b) == want_2t
+        # a dealer whose two sharings hide DIFFERENT secrets (double_share_generation.rs deals the same one): the verifiers'
+        # equal-secret test (ran_dou_sha/mod.rs:588) must fail, and the oracle agrees
+        c2t[2][1][0] = (c2t[2][1][0] + 1) % S.R_MOD
+        _, _, ok_bad = S.randousha(ct, c2t, n, t)
+        assert not any(ok_bad)
+        rd.upload(to_dev([c for row in ct for poly in row for c in poly]), to_dev([c for row in c2t for poly in row for c in poly]))
+        with pytest.raises(RuntimeError, match="RanDouSha"):
+            rd.run(check=True)
+        bad, first = rd._bad()
+        assert bad == n - (t + 1) and first == 1
+    finally:
+        rd.close()
+        eng.close()
+
+
+@pytest.mark.parametrize("n,t,groups", [(4, 1, 3), (7, 2, 4), (16, 5, 2)])
+def test_preprocessing_chain_from_dealers_to_triples(n, t, groups):
+    """dealers' polynomials -> RanSha -> a, b; DouSha + RanDouSha -> ([r]_t, [r]_2t); TripleGen -> [c]_t, nothing leaves the
+    device in between.  Checked against the oracle end to end: every party's c share equals the restatement's, and the
+    shares reconstruct to a * b."""
+    S = SFR
+    pkg = load_package()
+    eng = pkg.Engine(0)
+    N = groups * (2 * t + 1)
+    pre = pkg.pipelines.Preprocessing(eng, n, t, N)
+    rng = random.Random(n + 17 * groups)
+    try:
+        co = _coeffs(S, rng, n, pre.K_rs, t)
+        ct = _coeffs(S, rng, n, pre.K_rd, t)
+        c2t = _coeffs(S, rng, n, pre.K_rd, 2 * t, secrets=[[ct[p][k][0] for k in range(pre.K_rd)] for p in range(n)])
+        flat = lambda cc: ints_to_u256([c for row in cc for poly in row for c in poly])
+        pre.rs.upload(flat(co))
+        pre.rd.upload(flat(ct), flat(c2t))
+        pre.run(check=True)
+        c_dev = [u256_to_ints(r) for r in pre.tg.download_c()]
+        # the oracle: same producers, then triple_generation.rs per party and BatchRecon's opened values
+        rs_out, ok1 = S.ransha(co, n, t)
+        rt_out, r2t_out, ok2 = S.randousha(ct, c2t, n, t)
+        assert all(ok1) and all(ok2)
+        a = [rs_out[j][:N] for j in range(n)]
+        b = [rs_out[j][N:2 * N] for j in range(n)]
+        for k in range(N):
+            masked = [S.Share((a[j][k] * b[j][k] - r2t_out[j][k]) % S.R_MOD, j, 2 * t) for j in range(n)]
+            poly, opened = S.recover_secret(masked, n, t)        # a b - r, a degree-2t sharing opened robustly
+            for j in range(n):
+                assert c_dev[j][k] == (rt_out[j][k] + opened) % S.R_MOD
+            # and the triple is a triple
+            sa = S.recover_secret([S.Share(a[j][k], j, t) for j in range(n)], n, t)[1]
+            sb = S.recover_secret([S.Share(b[j][k], j, t) for j in range(n)], n, t)[1]
+            sc = S.recover_secret([S.Share(c_dev[j][k], j, t) for j in range(n)], n, t)[1]
+            assert sc == sa * sb % S.R_MOD
+    finally:
+        pre.close()
+        eng.close()
