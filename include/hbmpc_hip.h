@@ -562,15 +562,14 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * matrix cores from 4 096 chunks, its decodes from 2 048 chunks when they are a single launch (exactly d + t + 1 senders)
  * and beyond the small-batch range (8 192 chunks) otherwise (csrc/kernels_mfma_gl.hpp: the table is a few KB, fits the
  * LDS whole and costs microseconds to build, so there is no sender-set rule).
- * min_chunks = 0 keeps the current thresholds.  Defaults: a decode of >= 65 536 chunks always takes the path (a sender
- * set not seen before costs ~0.7 ms of host table construction, more than a smaller call saves); a decode of
- * 4 096 .. 65 535 chunks -- from 2 048 when it is given exactly d + t + 1 senders, i.e. is a single launch -- takes it
- * when the sender set's table is already cached, and builds it the SECOND time the set is seen (a set seen once stays
- * with the lane kernels); evaluations (one table per (n, d), never rebuilt) take it from
- * 2 049 chunks, i.e. right above the wave-per-chunk kernel's range -- on domains beyond 16 points at every size, on
- * smaller domains while a workgroup has at most two tiles (16 384 chunks on 256 CUs; beyond that the single-pass FFT).  A nonzero min_chunks sets the first threshold and caps the other
- * two at it -- e.g. (1, 4096) before the eager run that precedes a graph capture makes mid-size decodes build their
- * table at once (nothing can be built during capture: a call whose table is missing then records the lane kernels). */
+ * min_chunks = 0 keeps the current thresholds.  Defaults: a decode takes the path from 4 096 chunks -- from 2 048 when it
+ * is given exactly d + t + 1 senders, i.e. is a single launch -- whether or not its sender set has been seen before: the
+ * set's byte-digit table (239 KB for n = 31) is expanded ON THE DEVICE from the rows x (d + 1) coefficients the host
+ * computes (csrc/kernels_tables.hpp; a first call costs 1.1 - 1.4x a repeat at 8 192 chunks); evaluations (one table per
+ * (n, d), never rebuilt) take it from 2 049 chunks, i.e. right above the wave-per-chunk kernel's range -- on domains
+ * beyond 16 points at every size, on smaller domains while a workgroup has at most two tiles (16 384 chunks on 256 CUs;
+ * beyond that the single-pass FFT).  A nonzero min_chunks caps these thresholds at it.  Nothing can be built during a
+ * graph capture: a call whose table is missing then records the lane kernels, so run the sequence once eagerly first. */
 ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);
 /* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have
  * arrived (batch_recon.rs:371-389) -- has no OEC round: a chunk that fails the verification can only fail
@@ -581,6 +580,11 @@ ShareErrorCode hbmpc_set_single_launch_decode(hbmpc_ctx* ctx, int on);
 /* test aid: workgroups of a matrix-core launch (0 = one per CU, the default); a small number makes a small batch walk
  * the multi-tile loop of every wave */
 ShareErrorCode hbmpc_set_matrix_core_workgroups(hbmpc_ctx* ctx, int workgroups);
+/* test aid: the matrix-core byte-digit table of a sender set (ids ascending) exactly as the library builds it: expanded on
+ * the device from the host-computed coefficients (on_device != 0: what a decode uses) or by the host reference the CPU
+ * tests pin against the oracle.  *bytes_out = its size; out (nullable) receives it when cap suffices. */
+ShareErrorCode hbmpc_debug_mfma_table(hbmpc_ctx* ctx, const size_t* sorted_ids, size_t S, size_t n, size_t d, size_t t, int on_device,
+                                      uint8_t* out, size_t cap, size_t* bytes_out);
 /* test aid: 1 = route every shape through the generic (runtime-shaped) kernels */
 ShareErrorCode hbmpc_set_force_generic(hbmpc_ctx* ctx, int on);
 /* Secret hygiene.  The host-pointer calls stage their arguments through per-context pools (device buffers, pinned host

@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <future>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -54,15 +56,17 @@ struct hbmpc_ctx {
     bool direct_fail = true;                       // a decode with no OEC round (S == d + t + 1) is ONE launch: failures are written by the first kernel
     bool zero_copy = true;                         // small host-pointer calls stage through mapped host memory
     bool matrix_cores = true;                      // large Fr decodes run the int8 MFMA formulation (kernels_mfma.hpp)
-    size_t mfma_min_chunks = 65536;                // ... from this many chunks on (a new sender set costs ~1 ms of host table)
-    size_t mfma_min_cached = 4096;                 // ... and from this many when the sender set's table is cached or the set recurs
+    size_t mfma_min_chunks = 65536;                // A/B aid since the tables are expanded on the device: the thresholds below decide
+    size_t mfma_min_cached = 4096;                 // ... from this many chunks on (the crossover with the wave-per-chunk kernels)
     size_t mfma_min_direct = 2048;                 // ... and from this many when the call has no OEC round (one launch)
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
+    bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
     size_t mfma_min_gold = 4096;                   // Goldilocks encodes (tiny tables, one workgroup kind): from this many chunks
     size_t mfma_min_gold_direct = 2048;            // Goldilocks decodes without OEC rounds (one launch): flat ~7 us against a wave-per-chunk kernel that grows
     size_t mfma_min_gold_oec = 8193;               // Goldilocks decodes with OEC rounds (four launches against the small-batch path's two): beyond its range
-    std::map<std::string, int> mfma_seen;          // sender sets of mid-size decodes that went to the lane kernels, by sightings
+    std::map<size_t, std::shared_ptr<DomainInv<HFr>>> dom_fr;  // per n: domain elements + inverse differences (tables.hpp), built once
+    std::map<size_t, std::shared_ptr<DomainInv<HGl>>> dom_gl;
     int n_cus = 256;
     int mfma_wgs = 0;                              // test aid: workgroups of a matrix-core launch (0 = one per CU)
     std::map<hipStream_t, Scratch> scratch;        // per-stream scratch (calls on one stream are ordered)
@@ -144,18 +148,50 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
     *out = dev;
     return ShareSuccess;
 }
-// Is `key` cached?  If not, count the sighting and say how many there have been (the matrix-core decode builds its table
-// for a mid-size batch only when the sender set comes back: capi_recover.inc).
-static bool table_cached_or_count(hbmpc_ctx* ctx, const std::string& key, int* sightings) {
+// A table whose bulk is EXPANDED ON THE DEVICE from a small host-built seed (the matrix-core byte-digit table: a few KB of
+// coefficients -> hundreds of KB): the entry is dev_words of table followed by the seed; `expand` enqueues the kernels on
+// the context's own stream, which is drained before the entry is published -- so whichever stream or thread uses the
+// entry next is ordered behind the build by the host, and the caller's stream is never waited for.
+template <class Build, class Expand>
+static ShareErrorCode get_table_expanded(hbmpc_ctx* ctx, const std::string& key, size_t dev_words, Build build_seed, Expand expand,
+                                         const uint32_t** out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->tables.find(key) != ctx->tables.end()) return true;
-    if (g_capturing) {
-        *sightings = 0;  // nothing may be built now: the call takes the kernels whose tables the eager run built
-        return false;
+    auto it = ctx->tables.find(key);
+    if (it != ctx->tables.end()) {
+        if (g_capturing) it->second.pinned = true;
+        *out = it->second.p;
+        return ShareSuccess;
     }
-    if (ctx->mfma_seen.size() >= 4096) ctx->mfma_seen.clear();
-    *sightings = ++ctx->mfma_seen[key];
-    return false;
+    if (g_capturing) return fail(ctx, HBMPC_NO_DEVICE, "a table would have to be built during graph capture: run the call sequence once eagerly first");
+    if (ctx->tables.size() >= 512) {  // same two-phase flush as get_table
+        ++ctx->evictions;
+        (void)hipDeviceSynchronize();
+        for (uint32_t* q : ctx->retired_tables) (void)hipFree(q);
+        ctx->retired_tables.clear();
+        for (auto t = ctx->tables.begin(); t != ctx->tables.end();) {
+            if (t->second.pinned) {
+                ++t;
+                continue;
+            }
+            ctx->retired_tables.push_back(t->second.p);
+            t = ctx->tables.erase(t);
+        }
+    }
+    std::vector<uint32_t> seed = build_seed();
+    uint32_t* dev = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dev, (dev_words + seed.size() + 16) * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(dev + dev_words, seed.data(), seed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    expand(dev, dev + dev_words, ctx->stream);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    hbmpc_ctx::Tab& tab = ctx->tables[key];
+    tab.p = dev;
+    *out = dev;
+    return ShareSuccess;
+}
+static bool table_cached(hbmpc_ctx* ctx, const std::string& key) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return ctx->tables.find(key) != ctx->tables.end();
 }
 // Per-stream scratch from plain hipMalloc.  NOT hipMallocAsync: data written to stream-ordered-pool memory by
 // one kernel was observed stale for workgroups of the NEXT kernel that run on other XCDs (their L2 kept the

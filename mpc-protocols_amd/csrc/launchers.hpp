@@ -103,6 +103,8 @@ void launch_unpack_shares(const uint64_t* payload, size_t N, uint64_t id, uint64
                           uint32_t* status, hipStream_t s);
 void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hipStream_t s);
 void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s);
+void launch_mfma_table(const uint64_t* coeff, int m, int rows, const uint64_t e[4], uint32_t bmag, uint8_t* table, uint64_t* partial,
+                       hipStream_t s);  // kernels_tables.hpp
 // layout + verdict kernels of the preprocessing producers (kernels_codec.hpp); ew64 = 64-bit words per element
 void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, size_t src_row_stride, uint64_t* dst, size_t dst_row_stride,
                       size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s);

@@ -128,8 +128,80 @@ inline std::vector<uint32_t> build_pow2(size_t m, int impl) {
     return out;
 }
 
-// Lagrange basis over the points xs (distinct): basis[i][k] = coefficient k of
-// L_i(x) = A(x) / ((x - x_i) A'(x_i)),  A = prod (x - x_j)     (robust_interpolate.rs:351-376)
+// Everything a sender set's tables need from the evaluation domain, computed ONCE per n: the size elements alpha_k and
+// E[k] = 1 / (alpha_k - 1), k >= 1 (one field inversion for all of them).  A difference of two domain elements is
+// alpha_a - alpha_b = alpha_b (alpha_{a-b} - 1), so its inverse is alpha_{size-b} E[a-b]: no table of a sender set needs a
+// field inversion (a Fermat inversion is ~380 multiplications -- it used to be most of a small set's Lagrange basis).
+template <class H>
+struct DomainInv {
+    size_t n = 0, size = 0;
+    std::vector<H> el, E;
+    explicit DomainInv(size_t n_) : n(n_), size(domain_size(n_)) {
+        el = domain_elements<H>(n_, size);
+        E.assign(size, H::zero());
+        if (size < 2) return;
+        std::vector<H> pre(size);
+        H run = H::one();
+        for (size_t k = 1; k < size; ++k) {
+            pre[k] = run;
+            run = run * (el[k] - H::one());
+        }
+        H all = run.inv();
+        for (size_t k = size; k-- > 1;) {
+            E[k] = all * pre[k];
+            all = all * (el[k] - H::one());
+        }
+    }
+    // 1 / (alpha_a - alpha_b), a != b
+    H dinv(size_t a, size_t b) const { return el[(size - b) % size] * E[(a + size - b) % size]; }
+};
+
+// Lagrange basis over the domain points with the given ids (distinct): basis[i][k] = coefficient k of
+// L_i(x) = A(x) / ((x - x_i) A'(x_i)),  A = prod (x - x_j)     (robust_interpolate.rs:351-376).
+// A_out (optional): the m + 1 coefficients of A; invden_out (optional): 1 / A'(x_i).
+template <class H>
+inline std::vector<std::vector<H>> lagrange_basis_ids(const DomainInv<H>& D, const size_t* ids, size_t m, std::vector<H>* A_out = nullptr,
+                                                      std::vector<H>* invden_out = nullptr) {
+    std::vector<H> A(m + 1, H::zero());
+    A[0] = H::one();
+    size_t deg = 0;
+    for (size_t j = 0; j < m; ++j) {  // A *= (x - x_j)
+        const H nx = D.el[ids[j]].neg();
+        A[deg + 1] = A[deg];
+        for (size_t k = deg; k > 0; --k) A[k] = A[k] * nx + A[k - 1];
+        A[0] = A[0] * nx;
+        ++deg;
+    }
+    std::vector<H> inv(m);
+    for (size_t i = 0; i < m; ++i) {  // 1 / A'(x_i) = prod_{j != i} 1 / (x_i - x_j)
+        H dd = H::one();
+        for (size_t j = 0; j < m; ++j)
+            if (j != i) dd = dd * D.dinv(ids[i], ids[j]);
+        inv[i] = dd;
+    }
+    std::vector<std::vector<H>> basis(m, std::vector<H>(m, H::zero()));
+    std::vector<H> q(m);
+    for (size_t i = 0; i < m; ++i) {
+        // synthetic division of A by (x - x_i): q[m-1] = A[m], q[k-1] = A[k] + x_i q[k]
+        const H xi = D.el[ids[i]];
+        q[m - 1] = A[m];
+        for (size_t k = m - 1; k > 0; --k) q[k - 1] = A[k] + xi * q[k];
+        for (size_t k = 0; k < m; ++k) basis[i][k] = q[k] * inv[i];
+    }
+    if (A_out) *A_out = A;
+    if (invden_out) *invden_out = inv;
+    return basis;
+}
+// L_i(x_s) for a domain point s OUTSIDE the set: A(x_s) / ((x_s - x_i) A'(x_i)) -- two products per value once
+// A(x_s) = prod_j (x_s - x_j) is known, instead of a Horner walk over the basis polynomial
+template <class H>
+inline void lagrange_eval_row(const DomainInv<H>& D, const size_t* ids, size_t m, const std::vector<H>& invden, size_t s_id, H* row) {
+    H As = H::one();
+    const H xs = D.el[s_id];
+    for (size_t j = 0; j < m; ++j) As = As * (xs - D.el[ids[j]]);
+    for (size_t i = 0; i < m; ++i) row[i] = As * invden[i] * D.dinv(s_id, ids[i]);
+}
+// the general form over arbitrary distinct points (one field inversion): what the tests of the host tables pin
 template <class H>
 inline std::vector<std::vector<H>> lagrange_basis(const std::vector<H>& xs) {
     const size_t m = xs.size();
@@ -143,9 +215,6 @@ inline std::vector<std::vector<H>> lagrange_basis(const std::vector<H>& xs) {
         A[0] = A[0] * nx;
         ++deg;
     }
-    // denominators A'(x_i) = prod_{j != i} (x_i - x_j), inverted all at once (Montgomery's trick: one field inversion
-    // per basis instead of one per point -- a Fermat inversion is ~380 multiplications, and the OEC tables need a
-    // basis per round)
     std::vector<H> den(m), pre(m), inv(m);
     for (size_t i = 0; i < m; ++i) {
         H dd = H::one();
@@ -166,7 +235,6 @@ inline std::vector<std::vector<H>> lagrange_basis(const std::vector<H>& xs) {
     std::vector<std::vector<H>> basis(m, std::vector<H>(m, H::zero()));
     std::vector<H> q(m);
     for (size_t i = 0; i < m; ++i) {
-        // synthetic division of A by (x - x_i): q[m-1] = A[m], q[k-1] = A[k] + x_i q[k]
         q[m - 1] = A[m];
         for (size_t k = m - 1; k > 0; --k) q[k - 1] = A[k] + xs[i] * q[k];
         for (size_t k = 0; k < m; ++k) basis[i][k] = q[k] * inv[i];
@@ -188,16 +256,14 @@ struct RecoverTables {
 //   rows [0, needed - m): verify rows, row s - m = (L_i(x_s))_i for the verify points s = m .. needed-1
 //   rows [needed - m, needed): coefficient rows, row k = (coefficient k of L_i)_i
 template <class H>
-inline std::vector<std::vector<H>> recover_coeff_rows(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t) {
+inline std::vector<std::vector<H>> recover_coeff_rows(const DomainInv<H>& D, const std::vector<size_t>& sorted_ids, size_t d, size_t t) {
     const size_t m = d + 1, needed = d + t + 1;
-    std::vector<H> el = domain_elements<H>(n, n);
-    std::vector<H> xs(m);
-    for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[i]];
-    auto basis = lagrange_basis(xs);
+    std::vector<H> invden;
+    auto basis = lagrange_basis_ids<H>(D, sorted_ids.data(), m, nullptr, &invden);
     std::vector<std::vector<H>> rows;
     for (size_t s = m; s < needed; ++s) {
         std::vector<H> row(m);
-        for (size_t i = 0; i < m; ++i) row[i] = horner(basis[i], el[sorted_ids[s]]);
+        lagrange_eval_row(D, sorted_ids.data(), m, invden, sorted_ids[s], row.data());
         rows.push_back(row);
     }
     for (size_t k = 0; k < m; ++k) {
@@ -207,16 +273,24 @@ inline std::vector<std::vector<H>> recover_coeff_rows(const std::vector<size_t>&
     }
     return rows;
 }
+template <class H>
+inline std::vector<std::vector<H>> recover_coeff_rows(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t) {
+    return recover_coeff_rows<H>(DomainInv<H>(n), sorted_ids, d, t);
+}
 template <class H = HFr>
-inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t, int impl) {
+inline RecoverTables build_recover_tables(const DomainInv<H>& D, const std::vector<size_t>& sorted_ids, size_t d, size_t t, int impl) {
     const size_t m = d + 1, needed = d + t + 1;
-    const auto rows = recover_coeff_rows<H>(sorted_ids, n, d, t);
+    const auto rows = recover_coeff_rows<H>(D, sorted_ids, d, t);
     RecoverTables T;
     for (size_t r = 0; r < needed - m; ++r)
         for (size_t i = 0; i < m; ++i) put_const(T.vm, rows[r][i], impl);
     for (size_t k = 0; k < m; ++k)
         for (size_t i = 0; i < m; ++i) put_const(T.bc, rows[needed - m + k][i], impl);
     return T;
+}
+template <class H = HFr>
+inline RecoverTables build_recover_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t t, int impl) {
+    return build_recover_tables<H>(DomainInv<H>(n), sorted_ids, d, t, impl);
 }
 
 // "Second chance" tables (kernels_recover.hpp, k_second_chance): for a window W of m consecutive sorted senders,
@@ -261,27 +335,30 @@ struct SecondTables {
     }
 };
 template <class H = HFr>
-inline SecondTables build_second_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t P, int impl) {
+inline SecondTables build_second_tables(const DomainInv<H>& D, const std::vector<size_t>& sorted_ids, size_t d, size_t P, int impl) {
     const size_t m = d + 1;
-    std::vector<H> el = domain_elements<H>(n, n);
     SecondTables T;
+    std::vector<H> row(m), invden;
     for (int wsi : second_windows(m, P)) {
         const size_t ws = (size_t)wsi;
-        std::vector<H> xs(m);
-        for (size_t i = 0; i < m; ++i) xs[i] = el[sorted_ids[ws + i]];
-        auto basis = lagrange_basis(xs);
+        auto basis = lagrange_basis_ids<H>(D, sorted_ids.data() + ws, m, nullptr, &invden);
         const int w = T.n_windows++;
         T.win_start[w] = wsi;
         T.ev_off[w] = (uint32_t)T.words.size();
         for (size_t s = 0; s < P; ++s) {
             if (s >= ws && s < ws + m) continue;
-            for (size_t i = 0; i < m; ++i) put_const(T.words, horner(basis[i], el[sorted_ids[s]]), impl);
+            lagrange_eval_row(D, sorted_ids.data() + ws, m, invden, sorted_ids[s], row.data());
+            for (size_t i = 0; i < m; ++i) put_const(T.words, row[i], impl);
         }
         T.bc_off[w] = (uint32_t)T.words.size();
         for (size_t k = 0; k < m; ++k)
             for (size_t i = 0; i < m; ++i) put_const(T.words, basis[i][k], impl);
     }
     return T;
+}
+template <class H = HFr>
+inline SecondTables build_second_tables(const std::vector<size_t>& sorted_ids, size_t n, size_t d, size_t P, int impl) {
+    return build_second_tables<H>(DomainInv<H>(n), sorted_ids, d, P, impl);
 }
 
 }  // namespace hbmpc

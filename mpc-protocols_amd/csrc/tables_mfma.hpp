@@ -93,6 +93,30 @@ inline void add_mod(uint64_t a[4], const uint64_t b[4]) {  // a <- a + b mod r (
 }
 }  // namespace mfdetail
 
+// (Bmag sum_b 256^b) mod r as canonical words: the constant of the bias digits (a function of m only)
+inline void mf_bias_e(size_t m, uint64_t e[4]) {
+    const HFr s256 = HFr::from_u64(256);
+    HFr acc = HFr::zero(), p = HFr::one();
+    for (int b = 0; b < 32; ++b) {
+        acc = acc + p;
+        p = p * s256;
+    }
+    acc = acc * HFr::from_u64(mf_bias_mag(m));
+    acc.to_canon(e);
+}
+// the rows x m coefficients as canonical words, row-major: the input of the device expansion (kernels_tables.hpp)
+inline std::vector<uint32_t> mf_coeff_words(const std::vector<std::vector<HFr>>& C, size_t m) {
+    std::vector<uint32_t> w;
+    w.reserve(C.size() * m * 8);
+    for (const auto& row : C)
+        for (size_t i = 0; i < m; ++i) {
+            uint64_t c[4];
+            row[i].to_canon(c);
+            for (int k = 0; k < 4; ++k) w.push_back((uint32_t)c[k]), w.push_back((uint32_t)(c[k] >> 32));
+        }
+    return w;
+}
+
 // C: rows x m coefficient matrix.  Returns rows * mf_row_bytes(m) bytes (as u32 words).
 inline std::vector<uint32_t> build_mfma_table(const std::vector<std::vector<HFr>>& C, size_t m) {
     const size_t RB = mf_row_bytes(m);

@@ -1,4 +1,5 @@
 #include "kernels_codec.hpp"
+#include "kernels_tables.hpp"
 #include "launchers.hpp"
 namespace hbmpc {
 void launch_pack_fvec(const uint64_t* rows, size_t row_stride, size_t G, size_t n_rows, uint64_t* payloads,
@@ -52,5 +53,14 @@ void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size
     const dim3 grid((unsigned)((G + 255) / 256));
     if (ew64 == 4) hipLaunchKernelGGL(k_check_double<4>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
     else hipLaunchKernelGGL(k_check_double<1>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
+}
+// the matrix-core byte-digit table expanded on the device from rows x m canonical coefficients (kernels_tables.hpp);
+// partial: rows * m scratch elements
+void launch_mfma_table(const uint64_t* coeff, int m, int rows, const uint64_t e[4], uint32_t bmag, uint8_t* table, uint64_t* partial,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(tb::k_mfma_table_slabs, dim3((unsigned)((rows * m + 63) / 64)), dim3(64), 0, s, coeff, m, rows, table, partial);
+    tb::TableE E;
+    for (int k = 0; k < 4; ++k) E.w[k] = e[k];
+    hipLaunchKernelGGL(tb::k_mfma_table_bias, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, s, partial, m, rows, E, bmag, table);
 }
 }
