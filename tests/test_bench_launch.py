@@ -39,9 +39,10 @@ def test_one_gpu_needs_no_launcher():
 
 
 def test_spawns_the_ranks_and_returns_their_exit_code():
-    # a real spawn: both ranks start, find no GPU and exit non-zero; the parent relays their stderr and their exit code
+    # a real spawn: the ranks start, find no GPU and exit non-zero (the launcher stops the others as soon as one has failed,
+    # so one message is guaranteed, not two); the parent relays their stderr and their exit code
     out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
                          env=_env(), timeout=600)
     assert out.returncode != 0
-    assert out.stderr.count("needs an MI355X") >= 2, out.stderr[-2000:]
+    assert out.stderr.count("needs an MI355X") >= 1, out.stderr[-2000:]
     assert out.stdout.strip() == ""  # no bench record
