@@ -83,10 +83,6 @@ HB_DEV void rt_dma16(const uint8_t* sbase, uint32_t voff, uint32_t lds_dst) {
 }
 HB_DEV void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-HB_DEV __amdgpu_buffer_rsrc_t rt_rsrc(const void* p, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
-constexpr uint32_t RT_OOB = 0xfffffff0u;  // beyond every buffer: the store is dropped
 // timing-only ablations of tools/ubench_mfma_rt.hip (results are wrong with any of them): 1 no epilogue, 2 no DMA inside the
 // loop, 4 no wait / flips, 8 no B operand reads, 16 no MFMAs, 32 no bias reloads
 #define RT_ABL(a, bit) ((ABL & (bit)) != 0)
@@ -127,140 +123,6 @@ struct RtState {
     __amdgpu_buffer_rsrc_t out_rsrc;
     uint32_t out_lane_stride;  // bytes between consecutive chunks of one output row
 };
-
-// The vector epilogue of a row (gather / verify / reduce of kernels_mfma.hpp) cut into micro-stages, which are dealt out
-// over the gaps between the M MFMAs of the next row by weight (~ instructions), so that no gap carries much more than
-// its share: an in-order wave cannot make up for a gap whose vector work outlasts its MFMA.
-constexpr int RT_NSTAGE = 13;
-constexpr int RT_STAGE_W[RT_NSTAGE] = {4, 4, 4, 4, 4, 1, 1, 2, 3, 3, 4, 4, 3};
-constexpr int rt_weight_before(int st) {
-    int w = 0;
-    for (int k = 0; k < st; ++k) w += RT_STAGE_W[k];
-    return w;
-}
-template <int M>
-constexpr int rt_stage_gap(int st) { return rt_weight_before(st) * M / rt_weight_before(RT_NSTAGE); }
-template <int M>
-constexpr int rt_bias_gap() {  // first gap after the one that reads the last sums (stage 1)
-    return rt_stage_gap<M>(1) + 1 < M ? rt_stage_gap<M>(1) + 1 : M - 1;
-}
-// One wave per SIMD has nobody to hide a dependent instruction's latency behind (v_mad_u64_u32: ~10 cycles against ~4 of
-// issue), so the instructions of a stage are independent of each other wherever the arithmetic allows (the four digit
-// groups side by side), and the carry ripple is three multiply-adds t_k = hi(t_{k-1}) * 1 + Q_k, one per gap, instead
-// of a v_addc chain with its wait states.
-struct RtEpi {
-    uint32_t p0[4], p1[4];
-    uint64_t T[4], Q[4];
-    uint32_t U[4];
-    uint32_t q, top, res, c;  // res: verify -> nonzero when the row disagrees; output -> nonzero when the fast reduction does not hold
-};
-// where the result of the row being finished goes
-struct RtRow {
-    uint32_t voff;  // output rows: byte offset of this lane's 16 bytes inside the row (RT_OOB: no store)
-    uint32_t soff;  // output rows: byte offset of the row
-    uint32_t mask;  // verify rows: all ones when the lane's verdict counts
-};
-template <bool VERIFY>
-HB_DEV void rt_epi_stage(int st, RtEpi& e, const v16i& acc, const v4i& ys, const RtRow& row, const Half& H, uint32_t one,
-                         const __amdgpu_buffer_rsrc_t& rsrc, uint32_t& bad) {
-    switch (st) {
-        case 0:
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e.p0[j] = ((uint32_t)acc[4 * j + 1] << 8) + (uint32_t)acc[4 * j];
-            break;
-        case 1:
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e.p1[j] = ((uint32_t)acc[4 * j + 3] << 8) + (uint32_t)acc[4 * j + 2];
-            break;
-        case 2:
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e.T[j] = (uint64_t)e.p1[j] * H.k16 + e.p0[j];
-            break;
-        case 3:
-            if constexpr (VERIFY) {
-                e.q = low_bcast((uint32_t)e.T[0] - (uint32_t)ys[0]);  // r = 1 mod 2^32 (kernels_mfma.hpp)
-            } else {
-                const uint32_t xq = (uint32_t)(e.T[3] >> 17);
-                e.q = high_bcast(__umulhi(xq, Q_RECIP) >> 13);
-            }
-            break;
-        case 4:
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e.Q[j] = (uint64_t)e.q * H.nr[j] + e.T[j];
-            break;
-        case 5:
-            e.Q[1] = (uint64_t)(uint32_t)(e.Q[0] >> 32) * one + e.Q[1];  // < 2^64: q NR_j + T_j + 2^32 stays below it for every q that can pass (kernels_mfma.hpp)
-            break;
-        case 6:
-            e.Q[2] = (uint64_t)(uint32_t)(e.Q[1] >> 32) * one + e.Q[2];
-            break;
-        case 7:
-            e.Q[3] = (uint64_t)(uint32_t)(e.Q[2] >> 32) * one + e.Q[3];
-            e.top = (uint32_t)(e.Q[3] >> 32);
-            break;
-        case 8:
-            e.res = low_bcast(e.top) & H.hmask;  // carry into the high half
-            break;
-        case 9:
-            e.U[0] = __builtin_addc((uint32_t)e.Q[0], e.res, 0u, &e.c);
-            e.U[1] = __builtin_addc((uint32_t)e.Q[1], 0u, e.c, &e.c);
-            break;
-        case 10:
-            e.U[2] = __builtin_addc((uint32_t)e.Q[2], 0u, e.c, &e.c);
-            e.U[3] = __builtin_addc((uint32_t)e.Q[3], 0u, e.c, &e.c);
-            e.top += e.c;
-            break;
-        case 11:
-            if constexpr (VERIFY) {
-                e.res = (e.U[0] ^ (uint32_t)ys[0]) | (e.U[1] ^ (uint32_t)ys[1]) | (e.U[2] ^ (uint32_t)ys[2]) | (e.U[3] ^ (uint32_t)ys[3]);
-            } else {
-                // exact when word 8 cancels and the top word is below r's (high half); the rest is repaired after the chain
-                e.res = (H.hmask != 0 && (e.top != e.q || e.U[3] >= R_TOP)) ? 1u : 0u;
-            }
-            break;
-        default:
-            if constexpr (VERIFY) {
-                bad |= (e.res | ((e.top ^ e.q) & H.hmask)) & row.mask;
-            } else {
-                v4i val;
-                val[0] = (int)e.U[0], val[1] = (int)e.U[1], val[2] = (int)e.U[2], val[3] = (int)e.U[3];
-                __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, (int)row.voff, (int)row.soff, 0);
-            }
-            break;
-    }
-}
-// the rare tail of reduce_tile: conditional subtractions where the fast path does not hold (wave-uniform branch by the caller)
-HB_DEV void rt_reduce_slow(RtEpi& e, const Half& H) {
-    uint32_t rw[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rw[j] = H.hmask ? R_W[4 + j] : R_W[j];
-    uint32_t ex = high_bcast(e.top - e.q);
-    for (int it = 0; it < 5; ++it) {
-        uint32_t Dw[4];
-        uint64_t b = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint64_t d = (uint64_t)e.U[j] - rw[j] - b;
-            Dw[j] = (uint32_t)d;
-            b = (d >> 32) & 1;
-        }
-        const uint32_t bin = low_bcast((uint32_t)b) & H.hmask;
-        uint64_t d = (uint64_t)Dw[0] - bin;
-        Dw[0] = (uint32_t)d;
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            d = (uint64_t)Dw[j] - ((d >> 32) & 1);
-            Dw[j] = (uint32_t)d;
-        }
-        const uint32_t bout = high_bcast((uint32_t)b + (uint32_t)((d >> 32) & 1));
-        const bool take = ex >= bout;
-        if (take) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e.U[j] = Dw[j];
-            ex -= bout;
-        }
-    }
-}
 
 struct RtCarry {
     v4i ys;      // claimed values of the carried row (verify waves)

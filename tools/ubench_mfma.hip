@@ -53,7 +53,7 @@ static float time_ms(F f, int reps) {
 }
 
 static int g_nwg = 256;  // workgroups per launch (one per CU: the table rows of a role fill most of the LDS)
-template <int M, int CG, int WAVES, int NR = 0, int ABL = 0>
+template <int M, int CG, int WAVES, int NR = 0, int ABL = 0, bool PIPE = false>
 static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     constexpr int ROWB = M * 1024 + 128;
     const int cap = (160 * 1024) / ROWB;
@@ -73,14 +73,14 @@ static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES, NR, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES, NR, ABL, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (NR > 0 && mf::mf_max_role_rows(a) > NR) {
         fprintf(stderr, "role rows %d exceed the static row count %d\n", mf::mf_max_role_rows(a), NR);
         exit(2);
     }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES, NR, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES, NR, ABL, PIPE>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 // encode x[G][M] with [I ; Cv] -> evals[M + nv][G]; decode with verify rows Cv and output rows Co; check vs host
@@ -221,6 +221,50 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
     const float ms_enc_s = time_ms([&] { launch_rows<M, CG, WAVES, (M == 11 ? 11 : 16)>(ea, n); }, reps);
     const float ms_dec_s = time_ms([&] { launch_rows<M, CG, WAVES, (M == 11 ? 11 : 16)>(ra, nv + M); }, reps);
     fprintf(stderr, "   static row count: encode %.4f -> %.4f ms, decode %.4f -> %.4f ms\n", ms_enc, ms_enc_s, ms_dec, ms_dec_s);
+    if constexpr (M == 11 && CG == 1) {
+        // the pipelined row loop (matrix pipe and vector epilogue overlapped inside the wave), 8 waves per workgroup: same bytes?
+        uint8_t *d_out2, *d_y2;
+        CK(hipMalloc(&d_out2, G * M * 32));
+        CK(hipMalloc(&d_y2, (size_t)n * G * 32));
+        CK(hipMemset(d_out2, 0xEE, G * M * 32));
+        CK(hipMemset(d_y2, 0xEE, (size_t)n * G * 32));
+        mf::MfmaRowsArgs rp2 = ra, ep2 = ea;
+        rp2.out = d_out2, ep2.out = d_y2;
+        launch_rows<M, 1, 8, 11, 0, true>(rp2, nv + M);
+        launch_rows<M, 1, 8, 11, 0, true>(ep2, n);
+        CK(hipDeviceSynchronize());
+        std::vector<uint8_t> h1(G * M * 32), h2(G * M * 32);
+        CK(hipMemcpy(h1.data(), d_out, h1.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h2.data(), d_out2, h2.size(), hipMemcpyDeviceToHost));
+        if (memcmp(h1.data(), h2.data(), h1.size()) != 0) {
+            size_t k = 0;
+            while (h1[k] == h2[k]) ++k;
+            fprintf(stderr, "%s: pipelined decode differs at byte %zu (chunk %zu coeff %zu)\n", name, k, k / (M * 32), (k / 32) % M);
+            ++errors;
+        }
+        std::vector<uint8_t> y1((size_t)n * G * 32), y2((size_t)n * G * 32);
+        CK(hipMemcpy(y1.data(), d_y, y1.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(y2.data(), d_y2, y2.size(), hipMemcpyDeviceToHost));
+        if (memcmp(y1.data(), y2.data(), y1.size()) != 0) {
+            fprintf(stderr, "%s: pipelined encode differs\n", name);
+            ++errors;
+        }
+        uint32_t cnt2[4];
+        CK(hipMemcpy(cnt2, d_cnt, 16, hipMemcpyDeviceToHost));
+        const float ms_dec_p = time_ms([&] { launch_rows<M, 1, 8, 11, 0, true>(rp2, nv + M); }, reps);
+        const float ms_enc_p = time_ms([&] { launch_rows<M, 1, 8, 11, 0, true>(ep2, n); }, reps);
+        const float ms_dec_8 = time_ms([&] { launch_rows<M, 1, 8, 11>(rp2, nv + M); }, reps);
+        const float ms_dec_p4 = time_ms([&] { launch_rows<M, 1, 4, 11, 0, true>(rp2, nv + M); }, reps);
+        const float ms_enc_p4 = time_ms([&] { launch_rows<M, 1, 4, 11, 0, true>(ep2, n); }, reps);
+        fprintf(stderr, "   pipelined row loop (4 waves, one per SIMD): decode %.4f ms, encode %.4f ms\n", ms_dec_p4, ms_enc_p4);
+        fprintf(stderr, "   pipelined row loop (8 waves): decode %.4f ms (same 8 waves without it: %.4f), encode %.4f ms; flagged so far %u\n", ms_dec_p,
+                ms_dec_8, ms_enc_p, cnt2[0]);
+        printf("{\"shape\": \"%s\", \"pipelined\": {\"decode_ms\": %.4f, \"decode_8_waves_unpipelined_ms\": %.4f, \"encode_ms\": %.4f}, \"unpipelined_%d_waves\": {\"decode_ms\": %.4f, \"encode_ms\": %.4f}, \"errors\": %d}\n",
+               name, ms_dec_p, ms_dec_8, ms_enc_p, WAVES, ms_dec_s, ms_enc_s, errors);
+        CK(hipMemset(d_cnt, 0, 16));
+        (void)hipFree(d_out2);
+        (void)hipFree(d_y2);
+    }
     mf::MfmaRowsArgs rp = ra;
     rp.table = d_tp0, rp.out_stride = 1;
     const float ms_p0 = time_ms([&] { launch_rows<M, CG, WAVES>(rp, nv + 1); }, reps);
