@@ -221,6 +221,40 @@ static int run_shape(const char* name, int nv, size_t G, int reps) {
     const float ms_enc_s = time_ms([&] { launch_rows<M, CG, WAVES, (M == 11 ? 11 : 16)>(ea, n); }, reps);
     const float ms_dec_s = time_ms([&] { launch_rows<M, CG, WAVES, (M == 11 ? 11 : 16)>(ra, nv + M); }, reps);
     fprintf(stderr, "   static row count: encode %.4f -> %.4f ms, decode %.4f -> %.4f ms\n", ms_enc, ms_enc_s, ms_dec, ms_dec_s);
+    if constexpr (M == 6 && CG == 1) {
+        // config 2's shape (16 rows x 6 inputs, one role): the pipelined row loop at 8 and 12 waves per workgroup
+        uint8_t* d_y2;
+        CK(hipMalloc(&d_y2, (size_t)n * G * 32));
+        CK(hipMemset(d_y2, 0xEE, (size_t)n * G * 32));
+        mf::MfmaRowsArgs ep2 = ea;
+        ep2.out = d_y2;
+        launch_rows<M, 1, 8, 16, 0, true>(ep2, n);
+        CK(hipDeviceSynchronize());
+        std::vector<uint8_t> y1((size_t)n * G * 32), y2((size_t)n * G * 32);
+        CK(hipMemcpy(y1.data(), d_y, y1.size(), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(y2.data(), d_y2, y2.size(), hipMemcpyDeviceToHost));
+        if (memcmp(y1.data(), y2.data(), y1.size()) != 0) {
+            size_t k = 0;
+            while (y1[k] == y2[k]) ++k;
+            fprintf(stderr, "%s: pipelined encode differs at byte %zu\n", name, k);
+            ++errors;
+        }
+        CK(hipMemset(d_y2, 0xEE, (size_t)n * G * 32));
+        launch_rows<M, 1, 12, 16, 0, true>(ep2, n);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(y2.data(), d_y2, y2.size(), hipMemcpyDeviceToHost));
+        if (memcmp(y1.data(), y2.data(), y1.size()) != 0) {
+            fprintf(stderr, "%s: pipelined encode (12 waves) differs\n", name);
+            ++errors;
+        }
+        const float p8 = time_ms([&] { launch_rows<M, 1, 8, 16, 0, true>(ep2, n); }, reps);
+        const float p12 = time_ms([&] { launch_rows<M, 1, 12, 16, 0, true>(ep2, n); }, reps);
+        const float u8 = time_ms([&] { launch_rows<M, 1, 8, 16>(ep2, n); }, reps);
+        const float u12 = time_ms([&] { launch_rows<M, 1, 12, 16>(ep2, n); }, reps);
+        fprintf(stderr, "   %d-row encode, pipelined row loop: 8 waves %.4f ms, 12 waves %.4f ms (unpipelined, static rows: 8 waves %.4f, 12 waves %.4f, %d waves %.4f)\n", n, p8, p12, u8, u12, WAVES, ms_enc_s);
+        printf("{\"shape\": \"%s\", \"encode_rows\": %d, \"pipelined_8_waves_ms\": %.4f, \"pipelined_12_waves_ms\": %.4f, \"unpipelined_8_waves_ms\": %.4f, \"unpipelined_12_waves_ms\": %.4f, \"unpipelined_%d_waves_ms\": %.4f, \"errors\": %d}\n", name, n, p8, p12, u8, u12, WAVES, ms_enc_s, errors);
+        (void)hipFree(d_y2);
+    }
     if constexpr (M == 11 && CG == 1) {
         // the pipelined row loop (matrix pipe and vector epilogue overlapped inside the wave), 8 waves per workgroup: same bytes?
         uint8_t *d_out2, *d_y2;
