@@ -557,7 +557,11 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * elements followed by one carry pass and one small-quotient reduction (csrc/kernels_mfma.hpp).  Results are
  * bit-identical to the lane-per-chunk kernels; on = 0 switches back to them (A/B aid, parity suites run both); on = 2
  * keeps the matrix cores but not the workgroup-per-tile kernel that batches with fewer 32-chunk tiles than waves take
- * (up to 16 384 chunks on a 256-CU chip: a tile's rows are shared by the waves of a workgroup instead of walked by one wave).
+ * (up to 16 384 chunks on a 256-CU chip: a tile's rows are shared by the waves of a workgroup instead of walked by one wave);
+ * on = 3 keeps the matrix cores but gives every evaluation point its own table row, where the default takes the points of
+ * a large encode in pairs (k, k + size/2) -- alpha_{k + size/2} = -alpha_k on a domain of roots of unity, so the even and
+ * the odd coefficients' digit sums are computed once and added / subtracted: half the matrix-core work and LDS operand
+ * traffic per output (csrc/kernels_mfma_bfly.hpp).
  * A Goldilocks context has the same switch: for 2 <= d + 1 <= 16 its encodes on domains beyond 16 points run on the
  * matrix cores from 4 096 chunks, its decodes from 2 048 chunks when they are a single launch (exactly d + t + 1 senders)
  * and beyond the small-batch range (8 192 chunks) otherwise (csrc/kernels_mfma_gl.hpp: the table is a few KB, fits the
@@ -567,8 +571,9 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * set's byte-digit table (239 KB for n = 31) is expanded ON THE DEVICE from the rows x (d + 1) coefficients the host
  * computes (csrc/kernels_tables.hpp; a first call costs 1.1 - 1.4x a repeat at 8 192 chunks); evaluations (one table per
  * (n, d), never rebuilt) take it from 2 049 chunks, i.e. right above the wave-per-chunk kernel's range -- on domains
- * beyond 16 points at every size, on smaller domains while a workgroup has at most two tiles (16 384 chunks on 256 CUs;
- * beyond that the single-pass FFT).  A nonzero min_chunks caps these thresholds at it.  Nothing can be built during a
+ * beyond 16 points at every size; on domains of 8 and 16 points at every size as well (the workgroup-per-tile kernel while
+ * a workgroup has at most two tiles -- 16 384 chunks on 256 CUs -- the point pairs beyond); 4-point domains keep the
+ * single-pass FFT beyond the workgroup-per-tile range.  A nonzero min_chunks caps these thresholds at it.  Nothing can be built during a
  * graph capture: a call whose table is missing then records the lane kernels, so run the sequence once eagerly first. */
 ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);
 /* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have

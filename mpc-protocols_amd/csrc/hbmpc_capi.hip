@@ -61,6 +61,7 @@ struct hbmpc_ctx {
     size_t mfma_min_direct = 2048;                 // ... and from this many when the call has no OEC round (one launch)
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
+    bool mfma_bfly = true;                         // large encodes take the domain points in pairs (kernels_mfma_bfly.hpp)
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
     size_t mfma_min_gold = 4096;                   // Goldilocks encodes (tiny tables, one workgroup kind): from this many chunks
     size_t mfma_min_gold_direct = 2048;            // Goldilocks decodes without OEC rounds (one launch): flat ~7 us against a wave-per-chunk kernel that grows
@@ -327,6 +328,7 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
     if (!ctx) return InvalidInput;
     ctx->matrix_cores = on != 0;
     ctx->mfma_team = on != 2;  // 2: without the workgroup-per-tile kernel of small batches (A/B aid)
+    ctx->mfma_bfly = on != 3;  // 3: large encodes with one table row per point instead of per point pair (A/B aid)
     if (min_chunks) {
         ctx->mfma_min_gold = std::min<size_t>(min_chunks, 4096);
         ctx->mfma_min_gold_direct = std::min<size_t>(min_chunks, 2048);
@@ -559,13 +561,13 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
     // (measured, 4 096 .. 16 384 chunks: n = 20, d = 6: 6.7 .. 10.0 us against 19 .. 20; n = 31, d = 10 -- three roles --
     // 9.8 and 15.1 us against 17.6 and 18.2 at 4 096 and 8 192 chunks, behind at 16 384)
     bool team = ctx->mfma_team && (G + 31) / 32 <= (size_t)nwg * 2;
-    if (!mf::mf_plan_roles((int)n, 0, (int)((160 * 1024 - (team ? 128 : 0)) / rowb), nwg, &a)) return false;
-    if (team && a.nroles > 1 && (G + 31) / 32 > (size_t)nwg) {
+    bool plain_ok = mf::mf_plan_roles((int)n, 0, (int)((160 * 1024 - (team ? 128 : 0)) / rowb), nwg, &a);
+    if (plain_ok && team && a.nroles > 1 && (G + 31) / 32 > (size_t)nwg) {
         team = false;
-        if (!mf::mf_plan_roles((int)n, 0, (int)((160 * 1024) / rowb), nwg, &a)) return false;
+        plain_ok = mf::mf_plan_roles((int)n, 0, (int)((160 * 1024) / rowb), nwg, &a);
     }
-    const uint32_t* tab;
-    *rc_out = get_table(ctx, key("mfvand", {n, dp1}, ctx->impl), [&] {
+    if (!plain_ok) team = false;  // the point pairs below may still fit (half the rows)
+    auto vandermonde = [&] {
         std::vector<HFr> el = domain_elements<HFr>(n, n);
         std::vector<std::vector<HFr>> V(n, std::vector<HFr>(dp1));
         for (size_t j = 0; j < n; ++j) {
@@ -575,16 +577,42 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
                 p = p * el[j];
             }
         }
-        return build_mfma_table(V, dp1);
-    }, &tab);
-    if (*rc_out != ShareSuccess) return true;
+        return V;
+    };
     a.G = G;
     a.in_chunk_major = 1;
-    a.table = (const uint8_t*)tab;
     a.nv = 0;
     a.out_party_major = 1;
     a.out_stride = y.ys ? y.ys : G;
     const int mi = (int)dp1;
+    // Large batches take the points in pairs (k, k + size / 2): alpha_{k + size/2} = -alpha_k, so both outputs come from
+    // the same M MFMAs (kernels_mfma_bfly.hpp) -- config 2: 0.16 ms against 0.18, config 3's encode 0.32 against 0.50
+    // (profiles/r03_mfma_bfly_ubench.txt).  The workgroup-per-tile kernel keeps the plain rows.
+    const size_t half = domain_size(n) / 2;
+    if (!team && ctx->mfma_bfly && half >= 2 && n > half) {
+        mf::MfmaRowsArgs b = a;
+        if (mf::mf_plan_pairs((int)half, (int)((160 * 1024) / mf_bfly_row_bytes(dp1)), nwg, &b)) {
+            const uint32_t* tab;
+            *rc_out = get_table(ctx, key("mfbfly", {n, dp1}, ctx->impl), [&] { return build_mfma_bfly_table(vandermonde(), dp1, half); }, &tab);
+            if (*rc_out != ShareSuccess) return true;
+            b.table = (const uint8_t*)tab;
+            b.half = (int)half, b.nout = (int)n;
+            bool ok = true;
+            for (unsigned p = 0; p < y.parties && ok; ++p) {  // party-batched calls: one launch per party
+                b.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
+                b.out = (uint8_t*)y.y + (size_t)p * n * b.out_stride * 32;
+                ok = launch_mfma_bfly_a(mi, b, ctx->device, s) || launch_mfma_bfly_b(mi, b, ctx->device, s) ||
+                     launch_mfma_bfly_c(mi, b, ctx->device, s) || launch_mfma_bfly_d(mi, b, ctx->device, s);
+                if (!ok && p > 0) return false;  // cannot happen: the first party's launch decides
+            }
+            if (ok) return true;
+        }
+    }
+    if (!plain_ok) return false;
+    const uint32_t* tab;
+    *rc_out = get_table(ctx, key("mfvand", {n, dp1}, ctx->impl), [&] { return build_mfma_table(vandermonde(), dp1); }, &tab);
+    if (*rc_out != ShareSuccess) return true;
+    a.table = (const uint8_t*)tab;
     // party-batched calls (x[P][G][d+1] -> y[P][n][G]): one launch per party (each is >= tens of microseconds)
     for (unsigned p = 0; p < y.parties; ++p) {
         a.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
@@ -654,6 +682,11 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
     if (impl == IMPL_U29 && size <= 16 && ctx->matrix_cores && ctx->mfma_team && !ctx->force_generic && y.parties == 1 && dp1 >= 2 &&
         dp1 <= MF_MAX_M && G >= ctx->mfma_min_encode && (G + 31) / 32 <= (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
         try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf))
+        return rc_mf;
+    // large batches on small domains: with the points taken in pairs the matrix-core encode is ahead of the single-pass FFT
+    if (impl == IMPL_U29 && size <= 16 && size >= 8 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && y.parties <= 64 &&
+        dp1 >= 2 && dp1 <= MF_MAX_M && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
+        G * std::max(dp1, (size_t)1) * 32 < ((size_t)1 << 32) && try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf))
         return rc_mf;
     if ((impl == IMPL_U29 || gold) && size <= 16 && !ctx->force_generic) {
         const uint32_t* tw;

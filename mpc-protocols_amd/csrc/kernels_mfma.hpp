@@ -79,6 +79,11 @@ HB_DEV void gather(const v16i& acc, uint64_t (&T)[4], const Half& H) {
         T[j] = (uint64_t)p1 * H.k16 + p0;
     }
 }
+// the digit pairs alone (kernels_mfma_bfly.hpp adds / subtracts two accumulators at this level: 8 values instead of 16)
+HB_DEV void gather_pairs(const v16i& acc, uint32_t (&p)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = ((uint32_t)acc[2 * j + 1] << 8) + (uint32_t)acc[2 * j];
+}
 // U = S + q (2^256 - r) for S = sum T[j] 2^(32 j) of both halves.  On return the high half holds words 4..7 of U and
 // `top` = everything above 2^256; the low half words 0..3 (its `top` already handed to the high half).
 HB_DEV void add_q_nr(uint32_t q, const uint64_t (&T)[4], uint32_t (&U)[4], uint32_t& top, const Half& H) {
@@ -110,10 +115,14 @@ HB_DEV uint32_t verify_tile(const v16i& acc, const v4i& ys, const Half& H) {
     return bad;
 }
 // canonical residue of the digit sums: this half's 4 words in Rw
+HB_DEV void reduce_words(const uint64_t (&T)[4], uint32_t (&Rw)[4], const Half& H);
 HB_DEV void reduce_tile(const v16i& acc, uint32_t (&Rw)[4], const Half& H) {
     uint64_t T[4];
-    uint32_t top;
     gather(acc, T, H);
+    reduce_words(T, Rw, H);
+}
+HB_DEV void reduce_words(const uint64_t (&T)[4], uint32_t (&Rw)[4], const Half& H) {
+    uint32_t top;
     // the high half estimates the quotient from its top word alone: T[3] >> 17 <= (sum >> 241), so never too large
     const uint32_t xq = (uint32_t)(T[3] >> 17);
     const uint32_t q = high_bcast(__umulhi(xq, Q_RECIP) >> 13);
@@ -347,6 +356,7 @@ struct MfmaRowsArgs {
     MfmaRole role[MF_MAX_ROLES];
     int direct;           // 1 (decode, ONE role): no OEC round exists, a chunk that fails the verification fails for good and this
                           // kernel is the whole call (kernels_recover.hpp: fail_chunk / count_failures / finish_direct)
+    int half, nout;       // kernels_mfma_bfly.hpp only: table rows are point PAIRS (k, k + half), outputs k + half >= nout do not exist
 };
 
 // NR > 0: every role of the launch has at most NR rows and the row loop is unrolled NR times with a compile-time trip
@@ -667,24 +677,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     if (a.direct) finish_direct(a.counters, a.summary);
 }
 
-// Host side: cut `rows` table rows (the first nv of them verify rows) into roles of at most `cap` rows.  Everything in one
-// role when it fits; otherwise the verify rows form role 0 and the output rows are cut evenly into as few roles as
-// possible.  nwg workgroups (rounded down to blocks of 8, at most 64 blocks) are shared in proportion to the rows.
-// Returns false when the verify rows do not fit one role (the caller then uses the lane-per-chunk kernels).
-inline bool mf_plan_roles(int rows, int nv, int cap, int nwg, MfmaRowsArgs* a) {
-    if (cap < 1 || nv > cap || rows < 1) return false;
-    int nroles = 0;
-    if (rows <= cap) {
-        a->role[nroles++] = MfmaRole{0, rows};
-    } else {
-        if (nv > 0) a->role[nroles++] = MfmaRole{0, nv};
-        const int ow = rows - nv, parts = (ow + cap - 1) / cap, per = (ow + parts - 1) / parts;
-        for (int r = nv; r < rows; r += per) {
-            if (nroles == MF_MAX_ROLES) return false;
-            a->role[nroles++] = MfmaRole{r, rows - r < per ? rows - r : per};
-        }
-    }
-    a->nroles = nroles;
+// nwg workgroups (rounded down to blocks of 8, at most 64 blocks) shared among the roles already in a->role[0 .. a->nroles)
+// in proportion to their rows
+inline bool mf_deal_blocks(int rows, int nwg, MfmaRowsArgs* a) {
+    const int nroles = a->nroles;
     int nblocks = nwg / 8;
     nblocks = nblocks > 64 ? 64 : nblocks < nroles ? nroles : nblocks;
     a->nblocks = nblocks;
@@ -706,6 +702,37 @@ inline bool mf_plan_roles(int rows, int nv, int cap, int nwg, MfmaRowsArgs* a) {
         a->role_nwg[k] = have[k] * 8;
     }
     return true;
+}
+// Host side: cut `rows` table rows (the first nv of them verify rows) into roles of at most `cap` rows.  Everything in one
+// role when it fits; otherwise the verify rows form role 0 and the output rows are cut evenly into as few roles as
+// possible.  nwg workgroups (rounded down to blocks of 8, at most 64 blocks) are shared in proportion to the rows.
+// Returns false when the verify rows do not fit one role (the caller then uses the lane-per-chunk kernels).
+inline bool mf_plan_roles(int rows, int nv, int cap, int nwg, MfmaRowsArgs* a) {
+    if (cap < 1 || nv > cap || rows < 1) return false;
+    int nroles = 0;
+    if (rows <= cap) {
+        a->role[nroles++] = MfmaRole{0, rows};
+    } else {
+        if (nv > 0) a->role[nroles++] = MfmaRole{0, nv};
+        const int ow = rows - nv, parts = (ow + cap - 1) / cap, per = (ow + parts - 1) / parts;
+        for (int r = nv; r < rows; r += per) {
+            if (nroles == MF_MAX_ROLES) return false;
+            a->role[nroles++] = MfmaRole{r, rows - r < per ? rows - r : per};
+        }
+    }
+    a->nroles = nroles;
+    return mf_deal_blocks(rows, nwg, a);
+}
+// the point pairs of kernels_mfma_bfly.hpp: `pairs` (a power of two) table rows in roles of EQUAL size, the largest power
+// of two that fits `cap` rows -- the kernel's unrolled pair loop has one trip count for every workgroup of a launch
+inline bool mf_plan_pairs(int pairs, int cap, int nwg, MfmaRowsArgs* a) {
+    if (cap < 1 || pairs < 1 || (pairs & (pairs - 1)) != 0) return false;
+    int per = pairs;
+    while (per > cap) per >>= 1;
+    if (per < 1 || pairs / per > MF_MAX_ROLES) return false;
+    a->nroles = pairs / per;
+    for (int k = 0; k < a->nroles; ++k) a->role[k] = MfmaRole{k * per, per};
+    return mf_deal_blocks(pairs, nwg, a);
 }
 inline int mf_grid(const MfmaRowsArgs& a) { return 8 * a.nblocks; }
 // can the pipelined instance <.., NR, .., PIPE = true> serve this plan?  every role of one kind of row, with nr or nr - 1 rows

@@ -1,0 +1,171 @@
+// kernels_mfma_bfly.hpp -- the encode (apply_vandermonde, common/share/mod.rs:50-76; compute_shares,
+// robust_interpolate.rs:52-82) on the matrix cores with HALF the MFMAs of kernels_mfma.hpp.
+//
+// The evaluation points are the powers of a root of unity of order size = 2 half (common/mod.rs:51-68), so
+// alpha_{k + half} = -alpha_k and, with the polynomial split by coefficient parity,
+//     p(alpha_k)        = E_k + T_k          E_k = sum_{i even} c_i alpha_k^i
+//     p(alpha_{k+half}) = E_k - T_k          T_k = sum_{i odd}  c_i alpha_k^i
+// E_k and T_k are constant-matrix maps of the even / odd coefficients: in the byte-digit formulation (tables_mfma.hpp)
+// their digit sums come from the SAME table slabs as row k of the plain kernel -- slab i goes to the accumulator of its
+// parity -- and the sum / difference is taken on the un-normalised digit sums (exact integers, far from overflow)
+// before the one carry pass and reduction each output needs anyway.  A pair of outputs so costs M MFMAs and M KB of
+// LDS operand traffic per 32 chunks instead of 2 M, plus 16 vector adds.
+//
+// Table row p (pair p): the M slabs of point p exactly as build_mfma_table lays them out, then two accumulator biases
+// [lane half][16] as int32: bE for the even accumulator and bT for the odd one, with bE + bT = the plain bias of row p and
+// bE - bT = a bias of row p + half (digit representation adjusted to the parity of the first, see
+// tables_mfma.hpp::build_mfma_bfly_table).  A point without a partner (p + half >= nout) has bT = 0 and no second output.
+#pragma once
+#include "kernels_mfma.hpp"
+
+namespace hbmpc {
+namespace mf {
+
+constexpr int MF_BFLY_BIAS = 256;
+
+// NP > 0: every role has exactly NP pairs (the host plans it so) and the pair loop is unrolled
+// ABL: timing-only ablations for tools/ubench_mfma_bfly.hip (the library's instances have ABL = 0): 1 = no epilogue arithmetic
+// (the stores stay), 2 = no MFMAs, 4 = no LDS operand reads either
+template <int M, int WAVES, int NP = 0, int ABL = 0>
+__global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
+    static_assert(M >= 2 && M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp)");
+    constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
+    constexpr int NT = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // role.nrows * ROWB
+    const int blk8 = (int)blockIdx.x >> 3, role_id = a.blk_role[blk8];
+    const int wg_in_role = (int)a.blk_idx[blk8] * 8 + ((int)blockIdx.x & 7);
+    MfmaRole role = a.role[0];
+    int role_wgs = a.role_nwg[0];
+#pragma unroll
+    for (int k = 1; k < MF_MAX_ROLES; ++k)
+        if (k == role_id) role = a.role[k], role_wgs = a.role_nwg[k];
+    {
+        const uint8_t* src = a.table + (size_t)role.row0 * ROWB;
+        const int pieces = role.nrows * (ROWB / 16);
+        for (int p = threadIdx.x; p < pieces; p += NT)
+            *reinterpret_cast<v4i*>(lds + (size_t)p * 16) = *reinterpret_cast<const v4i*>(src + (size_t)p * 16);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+    const Half H = make_half(h);
+    const size_t ntiles = (a.G + 31) / 32;
+    const size_t tstep = (size_t)role_wgs * WAVES;
+    // NP > 0: nothing inside the tile loop is conditional -- the next tile's loads are issued even past the end (clamped to
+    // the last chunk) and stores go through a buffer descriptor that drops what must not be written (dead lanes: an offset
+    // beyond the buffer; a partner point that does not exist: a buffer of zero bytes) -- so that hipcc knows how many vector
+    // memory operations follow a load and waits for a tile's inputs with vmcnt(stores + later loads) instead of vmcnt(0).
+    // vmcnt retires in order: with a conditional load or store in between, the wait for the OLDER input set also drains
+    // the set requested a moment ago, i.e. every other tile would pay a full HBM round trip.
+    constexpr bool STATIC = NP > 0;
+    auto load_inputs = [&](size_t t, v4i (&dst)[M]) {
+        const size_t gi = t * 32 + c;
+        const uint32_t g = (uint32_t)(gi < a.G ? gi : a.G - 1);
+#pragma unroll
+        for (int i = 0; i < M; ++i) dst[i] = *reinterpret_cast<const v4i*>(a.in + (size_t)i * 32 + (g * (M * 32u) + 16u * h));
+    };
+    const uint32_t row_bytes = (uint32_t)([&] {
+        const size_t b = a.out_party_major ? a.G * 32 : a.G * a.out_stride * 32;
+        return b < 0xffffffe0ull ? b : 0xffffffe0ull;
+    }());
+    auto store_row = [&](uint32_t k, bool exists, bool live, uint32_t qo, const uint32_t (&Rw)[4]) {
+        uint8_t* qb = a.out_party_major ? a.out + (size_t)k * a.out_stride * 32 : a.out + (size_t)k * 32;  // wave-uniform
+        if constexpr (STATIC) {
+            v4i val;
+            val[0] = (int)Rw[0], val[1] = (int)Rw[1], val[2] = (int)Rw[2], val[3] = (int)Rw[3];
+            __builtin_amdgcn_raw_buffer_store_b128(val, rt_rsrc(qb, exists ? row_bytes : 0u), (int)(live ? qo : RT_OOB), 0, 0);
+        } else {
+            if (exists && live) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+        }
+    };
+    auto process_tile = [&](size_t t, v4i (&data)[M]) {
+        const size_t gi = t * 32 + c;
+        const bool live = gi < a.G;
+        const uint32_t g = (uint32_t)(live ? gi : a.G - 1);
+#pragma unroll
+        for (int i = 0; i < M; ++i) data[i] = flip(data[i]);
+        const uint32_t qo = g * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
+#pragma unroll
+        for (int p = 0; p < (STATIC ? NP : role.nrows); ++p) {
+            const uint8_t* cur = lds + (size_t)p * ROWB;
+            v16i accE, accT;
+            {
+                const v4i* bp = reinterpret_cast<const v4i*>(cur + M * 1024 + h * 64);
+                const v4i e0 = bp[0], e1 = bp[1], e2 = bp[2], e3 = bp[3];
+                const v4i t0 = bp[8], t1 = bp[9], t2 = bp[10], t3 = bp[11];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    accE[k] = e0[k], accE[4 + k] = e1[k], accE[8 + k] = e2[k], accE[12 + k] = e3[k];
+                    accT[k] = t0[k], accT[4 + k] = t1[k], accT[8 + k] = t2[k], accT[12 + k] = t3[k];
+                }
+            }
+            {   // the M MFMAs: even inputs into accE, odd into accT (two independent chains); A operands three slabs ahead
+                constexpr int D = 3;
+                const uint8_t* tab_lane = cur + lane * 16;
+                v4i av[D];
+#pragma unroll
+                for (int i = 0; i < D - 1 && i < M; ++i) av[i] = *reinterpret_cast<const v4i*>(tab_lane + i * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    if (i + D - 1 < M && !(ABL & 4)) av[(i + D - 1) % D] = *reinterpret_cast<const v4i*>(tab_lane + (i + D - 1) * 1024);
+                    if (ABL & 2) {
+                        if (i & 1) accT[i] ^= av[i % D][0] & data[i][1];
+                        else accE[i] ^= av[i % D][0] & data[i][1];
+                    } else if (i & 1) accT = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i % D], data[i], accT, 0, 0, 0);
+                    else accE = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i % D], data[i], accE, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            uint32_t pe[8], pt[8];
+            gather_pairs(accE, pe);
+            gather_pairs(accT, pt);
+            uint32_t k32 = (uint32_t)(role.row0 + p);
+            asm volatile("" : "+s"(k32));  // the output row bases are recomputed, not kept per unrolled pair (scalar registers)
+            {
+                uint64_t T[4];
+                uint32_t Rw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] + pt[2 * j + 1]) * H.k16 + (pe[2 * j] + pt[2 * j]);
+                if (ABL & 1) Rw[0] = pe[0] + pt[1], Rw[1] = pe[2] + pt[3], Rw[2] = pe[4] + pt[5], Rw[3] = pe[6] + pt[7];
+                else reduce_words(T, Rw, H);
+                store_row(k32, true, live, qo, Rw);
+            }
+            const bool partner = (int)k32 + a.half < a.nout;
+            if (STATIC || partner) {
+                uint64_t T[4];
+                uint32_t Rw[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] - pt[2 * j + 1]) * H.k16 + (pe[2 * j] - pt[2 * j]);
+                if (ABL & 1) Rw[0] = pe[0] - pt[1], Rw[1] = pe[2] - pt[3], Rw[2] = pe[4] - pt[5], Rw[3] = pe[6] - pt[7];
+                else reduce_words(T, Rw, H);
+                store_row(k32 + (uint32_t)a.half, partner, live, qo, Rw);
+            }
+        }
+    };
+    // the tile loop of k_mfma_rows: two input register sets, the loads of a wave's NEXT tile issued before it starts on the
+    // current one
+    v4i setA[M], setB[M];
+    size_t t = (size_t)wg_in_role * WAVES + wave;
+    if (t < ntiles) load_inputs(t, setA);
+    if constexpr (STATIC) {
+        if (t < ntiles) {
+            // as many dropped stores as a tile issues: the loop header then sees the same queue behind the first input set
+            // on entry as on the back edge (hipcc merges the two states to the stricter wait)
+            const v4i z = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 2 * NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rt_rsrc(a.out, 0u), (int)RT_OOB, 0, 0);
+        }
+    }
+    while (t < ntiles) {
+        if (STATIC || t + tstep < ntiles) load_inputs(t + tstep, setB);
+        process_tile(t, setA);
+        t += tstep;
+        if (t >= ntiles) break;
+        if (STATIC || t + tstep < ntiles) load_inputs(t + tstep, setA);
+        process_tile(t, setB);
+        t += tstep;
+    }
+}
+
+}  // namespace mf
+}  // namespace hbmpc

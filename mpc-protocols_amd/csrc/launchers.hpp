@@ -75,6 +75,11 @@ bool launch_mfma_rows_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_
 bool launch_mfma_rows_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 bool launch_mfma_rows_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 bool launch_mfma_rows_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
+// the encode on a domain of roots of unity with the points taken in pairs (k, k + size / 2): half the MFMAs (kernels_mfma_bfly.hpp)
+bool launch_mfma_bfly_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
+bool launch_mfma_bfly_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
+bool launch_mfma_bfly_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
+bool launch_mfma_bfly_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 // small batches: one wave per chunk, one evaluation point / one table row per lane (k_eval_wide, k_batch_recover_wide)
 void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s);
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);

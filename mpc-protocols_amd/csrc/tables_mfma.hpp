@@ -176,4 +176,38 @@ inline std::vector<uint32_t> build_mfma_table(const std::vector<std::vector<HFr>
     return out;
 }
 
+// The pair table of kernels_mfma_bfly.hpp for the rows C[0 .. n) of a map whose rows k and k + half differ by the sign of
+// the odd columns (the Vandermonde rows of a domain of 2 half roots of unity).  Pair p < half: the slabs of row p, then
+// bE = (b_p + b') / 2 and bT = (b_p - b') / 2 with b_p the plain bias of row p and b' the plain bias of row p + half in a
+// digit representation of the same parity: adding r's bytes flips digit 0 (r is odd), and "digit b + 1, digit b - 1 - 256"
+// flips digit b alone; neither changes the value mod r, and the digit sums move by at most 512 -- inside the slack the
+// bound of the plain table leaves (|s d| <= 128 * 127 on the negative side).
+constexpr size_t MF_BFLY_BIAS_BYTES = 256;
+inline size_t mf_bfly_row_bytes(size_t m) { return m * 1024 + MF_BFLY_BIAS_BYTES; }
+inline std::vector<uint32_t> build_mfma_bfly_table(const std::vector<std::vector<HFr>>& C, size_t m, size_t half) {
+    const size_t n = C.size(), RB = mf_row_bytes(m), PB = mf_bfly_row_bytes(m), pairs = half < n ? half : n;
+    const std::vector<uint32_t> plain = build_mfma_table(C, m);
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(plain.data());
+    std::vector<uint32_t> out(pairs * PB / 4, 0u);
+    uint8_t* dst = reinterpret_cast<uint8_t*>(out.data());
+    for (size_t p = 0; p < pairs; ++p) {
+        memcpy(dst + p * PB, src + p * RB, m * 1024);
+        const int32_t* b1 = reinterpret_cast<const int32_t*>(src + p * RB + m * 1024);
+        int32_t* bE = reinterpret_cast<int32_t*>(dst + p * PB + m * 1024);
+        int32_t* bT = bE + 32;
+        if (p + half >= n) {
+            for (int b = 0; b < 32; ++b) bE[b] = b1[b], bT[b] = 0;
+            continue;
+        }
+        int32_t b2[32];
+        memcpy(b2, src + (p + half) * RB + m * 1024, sizeof b2);
+        if ((b1[0] ^ b2[0]) & 1)
+            for (int b = 0; b < 32; ++b) b2[b] += (int32_t)((HFr::MOD[b >> 3] >> (8 * (b & 7))) & 0xff);
+        for (int b = 1; b < 32; ++b)
+            if ((b1[b] ^ b2[b]) & 1) b2[b] += 1, b2[b - 1] -= 256;
+        for (int b = 0; b < 32; ++b) bE[b] = (b1[b] + b2[b]) / 2, bT[b] = (b1[b] - b2[b]) / 2;
+    }
+    return out;
+}
+
 }  // namespace hbmpc

@@ -135,7 +135,8 @@ class Engine:
 
     def set_matrix_cores(self, on: bool, min_chunks: int = 0):
         """large Fr decodes on the matrix cores (int8 MFMA); min_chunks = 0 keeps the current threshold"""
-        # on: False / True, or 2 = matrix cores without the workgroup-per-tile kernel of small batches (A/B)
+        # on: False / True, or 2 = matrix cores without the workgroup-per-tile kernel of small batches, 3 = large encodes with
+        # one table row per point instead of per point pair (both A/B aids)
         assert self.L.hbmpc_set_matrix_cores(self.ctx, C.c_int(int(on)), C.c_size_t(min_chunks)) == 0
 
     def scrub_staging(self):

@@ -1,0 +1,139 @@
+"""The matrix-core encode with the domain points taken in pairs (k, k + size/2), csrc/kernels_mfma_bfly.hpp: against the
+oracle, against the kernel with one table row per point (hbmpc_set_matrix_cores(ctx, 3, ..)) and against the FFT kernels.
+Covers every d + 1 it instantiates, points without a partner (n below the domain size), the unrolled pair loops (roles of
+4, 8 and 16 pairs) and the run-time one, several roles, ragged tails, few workgroups (a wave walks many tiles through both
+input register sets), strided output rows, party-batched calls and BASELINE configs[1] at full size.  Bar: bit-exact."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+from oracle import cref as O
+
+pytestmark = pytest.mark.gpu
+
+O_R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = load_package().Engine(0)
+    e.set_small_batch_chunks(0)
+    yield e
+    e.close()
+
+
+def rnd(seed, *shape):
+    return O.fill_random(seed, int(np.prod(shape))).reshape(*shape, 4)
+
+
+def polys(seed, G, d):
+    x = rnd(seed, G, d + 1)
+    x[0] = 0
+    x[1] = O.ints_to_u256([O_R - 1] * (d + 1))
+    x[2, :, :] = 0
+    x[2, d, 0] = 1
+    x[3] = O.ints_to_u256([(O_R - 1) if i & 1 else 0 for i in range(d + 1)])   # the odd half alone at its maximum
+    x[4] = O.ints_to_u256([0 if i & 1 else (O_R - 1) for i in range(d + 1)])   # the even half alone
+    return x
+
+
+def three_ways(eng, x, n, d):
+    out = []
+    for mode in (1, 3, 0):
+        eng.set_matrix_cores(mode, 1)
+        rc, y = eng.vandermonde_apply(x, n, d)
+        assert rc == 0
+        out.append(y)
+    eng.set_matrix_cores(1, 65536)
+    return out
+
+
+# (n, d): pairs per role / roles.  size <= 16 takes this kernel beyond the workgroup-per-tile range only (> 512 tiles)
+SHAPES = [(5, 1), (6, 2), (7, 2), (8, 3), (9, 1), (10, 3), (11, 4), (12, 5), (13, 4), (14, 6), (15, 7), (16, 5), (16, 8), (16, 10), (16, 14),
+          (17, 1), (20, 6), (24, 8), (31, 10), (31, 13), (31, 14), (32, 9), (33, 5), (40, 3), (40, 13), (63, 12), (64, 14), (64, 2), (100, 3)]
+
+
+@pytest.mark.parametrize("n,d", SHAPES)
+def test_point_pairs_vs_oracle_and_the_other_kernels(eng, n, d):
+    G = 16384 + 32 * 7 + 5   # 520 tiles: beyond the workgroup-per-tile kernel, last tile ragged
+    x = polys(1000 + 37 * n + d, G, d)
+    y_pairs, y_rows, y_fft = three_ways(eng, x, n, d)
+    rc0, y0 = O.vandermonde_apply(x, n, d)
+    assert rc0 == 0
+    assert np.array_equal(y_pairs, y0) and np.array_equal(y_rows, y0) and np.array_equal(y_fft, y0)
+
+
+@pytest.mark.parametrize("n,d", [(16, 5), (31, 10), (13, 4), (20, 6), (40, 3)])
+def test_few_workgroups_walk_many_tiles(eng, n, d):
+    """8 (16 with two roles) workgroups: every wave runs the tile loop many times, through both input register sets and the
+    counted waits between them"""
+    G = 40000 + 17
+    x = polys(7 * n + d, G, d)
+    eng.set_matrix_core_workgroups(8)
+    try:
+        y_pairs, y_rows, y_fft = three_ways(eng, x, n, d)
+    finally:
+        eng.set_matrix_core_workgroups(0)
+    rc0, y0 = O.vandermonde_apply(x, n, d)
+    assert rc0 == 0 and np.array_equal(y_pairs, y0) and np.array_equal(y_rows, y0) and np.array_equal(y_fft, y0)
+
+
+def test_strided_rows_and_party_batches(eng):
+    """the in-place wire path (output rows G + 8 apart: nothing written between them) and x[P][G][d+1] -> y[P][n][G]"""
+    import torch
+    dev = torch.device("cuda", 0)
+    for (n, d, G, P) in ((16, 5, 20000 + 9, 3), (31, 10, 17000 + 1, 2), (7, 2, 30000, 2)):
+        x = np.stack([polys(90 + p + n, G, d) for p in range(P)])
+        xd = torch.as_tensor(x.view(np.int64), device=dev).contiguous()
+        ystr = torch.full((n, G + 8, 4), -1, dtype=torch.int64, device=dev)
+        yp = torch.full((P, n, G, 4), -1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        eng.set_matrix_cores(1, 1)
+        assert eng.dev_vandermonde_apply_strided(xd[0].data_ptr(), G, n, d, ystr.data_ptr(), G + 8, 0) == 0
+        assert eng.dev_vandermonde_apply_parties(xd.data_ptr(), G, n, d, P, yp.data_ptr(), 0) == 0
+        eng.sync()
+        eng.set_matrix_cores(1, 65536)
+        for p in range(P):
+            rc0, y0 = O.vandermonde_apply(x[p], n, d)
+            assert rc0 == 0 and np.array_equal(yp[p].cpu().numpy().view(np.uint64), y0), (n, d, p)
+            if p == 0:
+                assert np.array_equal(ystr[:, :G].cpu().numpy().view(np.uint64), y0) and bool((ystr[:, G:] == -1).all())
+
+
+def test_full_size_config2(eng):
+    """BASELINE configs[1]: x[2^20][6] -> y[16][2^20], the point pairs against the FFT kernel (whole array) and against the oracle
+    (sampled chunks: both ends, tile boundaries, the wrap of a wave's tile walk)"""
+    import torch
+    n, d, G = 16, 5, 1 << 20
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC0FFEE12)
+    lo = torch.randint(0, 1 << 62, (G, d + 1, 3), dtype=torch.int64, device=dev, generator=gen)
+    hi = torch.randint(0, 0x73EDA753299D7D48, (G, d + 1, 1), dtype=torch.int64, device=dev, generator=gen)
+    x = torch.cat([lo, hi], dim=-1).contiguous()
+    ys = {}
+    for mode in (1, 0):
+        eng.set_matrix_cores(mode, 65536)
+        y = torch.full((n, G, 4), -1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        assert eng.dev_vandermonde_apply(x.data_ptr(), G, n, d, y.data_ptr(), 0) == 0
+        eng.sync()
+        ys[mode] = y
+    eng.set_matrix_cores(1, 65536)
+    assert torch.equal(ys[1], ys[0])
+    idx = np.unique(np.concatenate([np.arange(0, 70), np.arange(G - 70, G), np.arange(31, G, 32)[:40], np.arange(32 * 3072 - 3, 32 * 3072 + 3)]))
+    ti = torch.as_tensor(idx, device=dev)
+    rc0, y0 = O.vandermonde_apply(np.ascontiguousarray(x[ti].cpu().numpy().view(np.uint64)), n, d)
+    assert rc0 == 0 and np.array_equal(ys[1][:, ti].cpu().numpy().view(np.uint64), y0)
+    # linearity, a size-independent property: V(x + x') = V(x) + V(x') over the whole array
+    x2 = torch.roll(x, 1, 0).contiguous()
+    s_in = torch.empty_like(x)
+    s_out = torch.empty_like(ys[1])
+    y2 = torch.empty_like(ys[1])
+    assert eng.dev_fr_op("add", x.data_ptr(), x2.data_ptr(), G * (d + 1), s_in.data_ptr()) == 0
+    assert eng.dev_vandermonde_apply(x2.data_ptr(), G, n, d, y2.data_ptr(), 0) == 0
+    assert eng.dev_fr_op("add", ys[1].data_ptr(), y2.data_ptr(), n * G, s_out.data_ptr()) == 0
+    ysum = torch.empty_like(ys[1])
+    assert eng.dev_vandermonde_apply(s_in.data_ptr(), G, n, d, ysum.data_ptr(), 0) == 0
+    eng.sync()
+    assert torch.equal(ysum, s_out)

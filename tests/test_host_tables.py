@@ -163,3 +163,60 @@ def test_matrix_core_tables(dump, field, n, d, t, ids):
             bias = [int.from_bytes(raw[off + 4 * b: off + 4 * b + 4], "little", signed=True) for b in range(8)]
             assert all(0 < v < (1 << 23) for v in bias)
             assert (sum(v << (8 * b) for b, v in enumerate(bias)) - 128 * tsum) % P == 0, r
+
+
+@pytest.mark.parametrize("n,d,t,ids", [(4, 1, 1, [3, 0, 2, 1]), (7, 2, 2, [6, 5, 4, 3, 2]), (13, 4, 4, list(range(13))),
+                                       (16, 5, 5, list(range(16))), (16, 14, 0, list(range(16))), (31, 10, 10, list(range(31)))])
+def test_point_pair_tables_of_the_encode(dump, n, d, t, ids):
+    """tables_mfma.hpp::build_mfma_bfly_table (kernels_mfma_bfly.hpp): pair p holds the digit slabs of alpha_p^i and two
+    accumulator biases.  Checked here with integers: (1) the slabs are balanced digits of alpha_p^i 256^a; (2) bE + bT is a
+    bias of output p and bE - bT a bias of output p + size/2 (whose odd coefficients have the opposite sign); (3) for EVERY
+    input the two digit sums stay inside [0, 0xff0000) -- the interval the kernel's carry pass assumes -- by taking the
+    extreme of every product digit by digit."""
+    S, P = SFR, SFR.R_MOD
+    o = dump("fr", n, d, t, ids)
+    m = d + 1
+    assert "bfly_bytes" in o
+    if "bfly" not in o:
+        return
+    raw = b"".join(int(w, 16).to_bytes(4, "little") for w in o["bfly"][0].split())
+    size = 1
+    while size < n:
+        size <<= 1
+    half = size // 2
+    PB = m * 1024 + 256
+    assert len(raw) == half * PB
+    sb = lambda v: v - 256 if v >= 128 else v   # noqa: E731
+    for p in range(half):
+        alpha = S.domain_element(n, p)
+        dig = [[[sb(raw[p * PB + i * 1024 + (_row_of_digit(b) + 32 * (a >> 4)) * 16 + (a & 15)]) for b in range(32)] for a in range(32)]
+               for i in range(m)]  # dig[i][a][b]
+        tsum = [0, 0]
+        for i in range(m):
+            for a in range(32):
+                T = sum(v << (8 * b) for b, v in enumerate(dig[i][a]))
+                assert T % P == pow(alpha, i, P) * pow(256, a, P) % P, (p, i, a)
+                tsum[i & 1] += T
+        bE = [int.from_bytes(raw[p * PB + m * 1024 + 4 * b: p * PB + m * 1024 + 4 * b + 4], "little", signed=True) for b in range(32)]
+        bT = [int.from_bytes(raw[p * PB + m * 1024 + 128 + 4 * b: p * PB + m * 1024 + 132 + 4 * b], "little", signed=True) for b in range(32)]
+        val = lambda v: sum(x << (8 * b) for b, x in enumerate(v))   # noqa: E731
+        plus = [e + t_ for e, t_ in zip(bE, bT)]
+        minus = [e - t_ for e, t_ in zip(bE, bT)]
+        assert (val(plus) - 128 * (tsum[0] + tsum[1])) % P == 0, p
+        partner = p + half < n
+        if partner:
+            assert (val(minus) - 128 * (tsum[0] - tsum[1])) % P == 0, p
+        else:
+            assert all(v == 0 for v in bT)
+        # the signed data bytes s are in [-128, 127]: extremes of s * digit, digit by digit
+        for b in range(32):
+            lo = [0, 0]
+            hi = [0, 0]
+            for i in range(m):
+                for a in range(32):
+                    v = dig[i][a][b]
+                    lo[i & 1] += min(-128 * v, 127 * v)
+                    hi[i & 1] += max(-128 * v, 127 * v)
+            assert 0 <= plus[b] + lo[0] + lo[1] and plus[b] + hi[0] + hi[1] < 0xff0000, (p, b)
+            if partner:
+                assert 0 <= minus[b] + lo[0] - hi[1] and minus[b] + hi[0] - lo[1] < 0xff0000, (p, b)
