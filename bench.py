@@ -32,6 +32,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def encode_kernel_name(impl):
+    """the kernel one compute_shares launch of BASELINE configs[1] is (rocprofv3 --kernel-trace shows it under this name): the
+    matrix-core encode with the 16 domain points in 8 pairs for the default field arithmetic, the generic Horner kernel for
+    the saturated-limb cross-check"""
+    return "k_mfma_bfly<6,12,8>" if impl == "u29" else "k_eval_generic<Sat32>"
+
+
 def shard_range(total: int, rank: int, world: int):
     """contiguous batch shard of `rank`"""
     base, rem = divmod(total, world)
@@ -349,7 +356,7 @@ def bench_single_process(args, torch):
                    "field": "bls12-381 Fr", "parallelism": f"batch-sharded x{N}, ONE process with a context and a host thread per device, "
                                                              "no data-path collective", "field_impl": args.impl},
         "roofline": {"bound": "hbm", "achieved": algo / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": "k_eval_fft1<U29,4,6>",
+                     "frac": algo / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel": encode_kernel_name(args.impl),
                      "kernel_ms": kernel_ms, "algorithmic_bytes": algo, "note": "slowest device; per-device kernel_ms in per_device"},
         "recon": {"value": B * N * args.steps / rsecs, "unit": "recons/s", "ms_per_step": rsecs / args.steps * 1e3,
                   "roofline": {"bound": "hbm", "achieved": r_algo / (rkernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -531,7 +538,7 @@ def bench_metric(ctx):
                    "field_impl": args.impl},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_eval_fft1<U29,4,6>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
+                     "kernel": encode_kernel_name(args.impl), "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes,
                      "kernel_ms_source": "HIP events around the K timed launches themselves"},
     }
     rec = traffic_record(f"compute_shares_n{n}_d{d}_B2^{args.log2_batch}_{args.impl}")
