@@ -576,6 +576,18 @@ ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl);
  * single-pass FFT beyond the workgroup-per-tile range.  A nonzero min_chunks caps these thresholds at it.  Nothing can be built during a
  * graph capture: a call whose table is missing then records the lane kernels, so run the sequence once eagerly first. */
 ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks);
+/* A decode of a sender set the context has not seen before, with OEC rounds available (more than d + t + 1 senders):
+ * the tables only chunks that FAIL the verification read -- the Gao rounds' Lagrange bases and the second-chance windows
+ * (robust_interpolate.rs:589-593; 0.4 - 1.3 ms of host arithmetic for n = 31 .. 64) -- are built after the first kernel,
+ * and only if it flagged a chunk: the call looks at the flagged counter once (one synchronisation of its stream, in a
+ * call that would otherwise have spent far longer building).  With honest senders such a first call costs 1.6 - 2.5x a
+ * repeat at 64 chunks (4.6 - 36x with the tables built up front).
+ *   on = 1 (default): the host-pointer entry points (hbmpc_batch_recover*, which synchronise anyway);
+ *   on = 2: the hbmpc_dev_* entry points as well -- their first call with a new sender set then waits for its first kernel,
+ *           and a later graph capture of that call needs the tables, i.e. a warm-up run made with on = 0 (or bad data);
+ *   on = 0: everything up front, as rounds 1 and 2 did (A/B aid).
+ * Inside a graph capture nothing can be looked at and the tables must exist.  Results are identical in every mode. */
+ShareErrorCode hbmpc_set_lazy_fallback_tables(hbmpc_ctx* ctx, int on);
 /* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have
  * arrived (batch_recon.rs:371-389) -- has no OEC round: a chunk that fails the verification can only fail
  * (DecodingError, robust_interpolate.rs:625).  Such a call is ONE kernel launch: the decode kernel writes the failure

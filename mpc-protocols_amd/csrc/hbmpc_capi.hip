@@ -60,6 +60,7 @@ struct hbmpc_ctx {
     size_t mfma_min_cached = 4096;                 // ... from this many chunks on (the crossover with the wave-per-chunk kernels)
     size_t mfma_min_direct = 2048;                 // ... and from this many when the call has no OEC round (one launch)
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
+    int lazy_fallback_tables = 1;                  // a new sender set's OEC / Gao and second-chance tables are built when a chunk needs them: 1 = host-pointer calls, 2 = all
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
     bool mfma_bfly = true;                         // large encodes take the domain points in pairs (kernels_mfma_bfly.hpp)
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
@@ -338,6 +339,12 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
         ctx->mfma_min_direct = std::min<size_t>(min_chunks, 2048);
         ctx->mfma_min_encode = std::min<size_t>(min_chunks, 2049);
     }
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_lazy_fallback_tables(hbmpc_ctx* ctx, int on) {  // either field
+    if (!ctx) return InvalidInput;
+    if (on < 0 || on > 2) return InvalidInput;
+    ctx->lazy_fallback_tables = on;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_single_launch_decode(hbmpc_ctx* ctx, int on) {  // either field

@@ -142,6 +142,11 @@ class Engine:
     def scrub_staging(self):
         assert self.L.hbmpc_scrub_staging(self.ctx) == 0
 
+    def set_lazy_fallback_tables(self, on):
+        """a new sender set's OEC / Gao and second-chance tables are built only when the first kernel flagged a chunk:
+        0 = never, 1 = host-pointer calls (default), 2 = device-pointer calls as well"""
+        assert self.L.hbmpc_set_lazy_fallback_tables(self.ctx, C.c_int(int(on))) == 0
+
     def set_single_launch_decode(self, on: bool):
         assert self.L.hbmpc_set_single_launch_decode(self.ctx, C.c_int(1 if on else 0)) == 0
 
