@@ -363,8 +363,8 @@ struct MfmaRowsArgs {
 // count -- hipcc can then count the stores issued after the next tile's loads and wait with vmcnt(#stores) at the tile
 // boundary; with a run-time trip count it waits for vmcnt(0), i.e. for every store of the tile to complete.
 // ABL: timing-only ablations, instantiated by tools/ubench_mfma.hip alone (the library's instances have ABL = 0 and none
-// of that code): 1 = no epilogue arithmetic (loads and stores stay), 2 = no MFMAs, 4 = every tile re-reads the first tiles
-// (inputs stay in L2) and nothing is stored.
+// of that code): 1 = no epilogue arithmetic (loads and stores stay), 2 = no MFMAs (the inputs are folded into the accumulator
+// with one XOR each, so their loads stay), 4 = every tile re-reads the first tiles (inputs stay in L2) and nothing is stored.
 template <int M, int CG, int WAVES, int NR = 0, int ABL = 0, bool PIPE = false>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
     static_assert(M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp) and the sum below 2^273");
@@ -493,6 +493,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) acc[cg] = bias;
                 if (!(ABL & 2)) mfma_row<M, CG>(cur + lane * 16, data, acc);
+                else {  // the inputs stay live (their loads must not be optimised away with the MFMAs)
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg)
+#pragma unroll
+                        for (int i = 0; i < M; ++i) acc[cg][i & 15] ^= data[cg][i][(r + i) & 3];
+                }
             }
             if ((ABL & 1) && r < nver) {
 #pragma unroll
