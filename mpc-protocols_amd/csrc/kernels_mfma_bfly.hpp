@@ -25,8 +25,14 @@ constexpr int MF_BFLY_BIAS = 256;
 
 // NP > 0: every role has exactly NP pairs (the host plans it so) and the pair loop is unrolled
 // ABL: timing-only ablations for tools/ubench_mfma_bfly.hip (the library's instances have ABL = 0): 1 = no epilogue arithmetic
-// (the stores stay), 2 = no MFMAs, 4 = no LDS operand reads either
-template <int M, int WAVES, int NP = 0, int ABL = 0>
+// (the stores stay), 2 = no MFMAs, 4 = no LDS operand reads either, 8 = (TRIPLE) no field products
+// TRIPLE: the encode of triple generation -- the inputs are the local products c = a b - r2t of three arrays (triple_gen,
+// honeybadger/triple_gen/mod.rs:181-260: the shares of a b are masked with the degree-2t randomness before they are opened),
+// computed in this kernel: lane (chunk, h) multiplies the coefficients of its chunk whose index has parity h (Montgomery,
+// fr_u29.hpp) and one v_permlane32_swap per word hands the halves round so that every lane ends up with its 16 bytes of every
+// coefficient -- the B operands, without a trip through memory or the LDS.  The tile index then runs over parties x tiles
+// (x[P][G][M] -> y[P][n][G]).
+template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     static_assert(M >= 2 && M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp)");
     constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         const size_t b = a.out_party_major ? a.G * 32 : a.G * a.out_stride * 32;
         return b < 0xffffffe0ull ? b : 0xffffffe0ull;
     }());
-    auto store_row = [&](uint32_t k, bool exists, bool live, uint32_t qo, const uint32_t (&Rw)[4]) {
-        uint8_t* qb = a.out_party_major ? a.out + (size_t)k * a.out_stride * 32 : a.out + (size_t)k * 32;  // wave-uniform
+    auto store_row = [&](uint8_t* out, uint32_t k, bool exists, bool live, uint32_t qo, const uint32_t (&Rw)[4]) {
+        uint8_t* qb = a.out_party_major ? out + (size_t)k * a.out_stride * 32 : out + (size_t)k * 32;  // wave-uniform
         if constexpr (STATIC) {
             v4i val;
             val[0] = (int)Rw[0], val[1] = (int)Rw[1], val[2] = (int)Rw[2], val[3] = (int)Rw[3];
@@ -77,12 +83,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
             if (exists && live) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
         }
     };
-    auto process_tile = [&](size_t t, v4i (&data)[M]) {
+    // the pairs of one tile from its B operands (sign-flipped bytes)
+    auto pairs_of_tile = [&](size_t t, const v4i (&data)[M], uint8_t* out) {
         const size_t gi = t * 32 + c;
         const bool live = gi < a.G;
         const uint32_t g = (uint32_t)(live ? gi : a.G - 1);
-#pragma unroll
-        for (int i = 0; i < M; ++i) data[i] = flip(data[i]);
         const uint32_t qo = g * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
 #pragma unroll
         for (int p = 0; p < (STATIC ? NP : role.nrows); ++p) {
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] + pt[2 * j + 1]) * H.k16 + (pe[2 * j] + pt[2 * j]);
                 if (ABL & 1) Rw[0] = pe[0] + pt[1], Rw[1] = pe[2] + pt[3], Rw[2] = pe[4] + pt[5], Rw[3] = pe[6] + pt[7];
                 else reduce_words(T, Rw, H);
-                store_row(k32, true, live, qo, Rw);
+                store_row(out, k32, true, live, qo, Rw);
             }
             const bool partner = (int)k32 + a.half < a.nout;
             if (STATIC || partner) {
@@ -138,32 +143,119 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] - pt[2 * j + 1]) * H.k16 + (pe[2 * j] - pt[2 * j]);
                 if (ABL & 1) Rw[0] = pe[0] - pt[1], Rw[1] = pe[2] - pt[3], Rw[2] = pe[4] - pt[5], Rw[3] = pe[6] - pt[7];
                 else reduce_words(T, Rw, H);
-                store_row(k32 + (uint32_t)a.half, partner, live, qo, Rw);
+                store_row(out, k32 + (uint32_t)a.half, partner, live, qo, Rw);
             }
         }
     };
-    // the tile loop of k_mfma_rows: two input register sets, the loads of a wave's NEXT tile issued before it starts on the
-    // current one
-    v4i setA[M], setB[M];
-    size_t t = (size_t)wg_in_role * WAVES + wave;
-    if (t < ntiles) load_inputs(t, setA);
-    if constexpr (STATIC) {
-        if (t < ntiles) {
-            // as many dropped stores as a tile issues: the loop header then sees the same queue behind the first input set
-            // on entry as on the back edge (hipcc merges the two states to the stricter wait)
-            const v4i z = {0, 0, 0, 0};
+    auto process_tile = [&](size_t t, v4i (&data)[M]) {
 #pragma unroll
-            for (int k = 0; k < 2 * NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rt_rsrc(a.out, 0u), (int)RT_OOB, 0, 0);
+        for (int i = 0; i < M; ++i) data[i] = flip(data[i]);
+        pairs_of_tile(t, data, a.out);
+    };
+    auto dropped_stores = [&] {
+        // as many dropped stores as a tile issues: the loop header then sees the same queue behind the first loads on entry
+        // as on the back edge (hipcc merges the two states to the stricter wait)
+        const v4i z = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 2 * NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rt_rsrc(a.out, 0u), (int)RT_OOB, 0, 0);
+    };
+    if constexpr (TRIPLE) {
+        using F = U29;
+        constexpr int NS = (M + 1) / 2;  // slots: slot j holds coefficient 2 j + h of this lane's chunk
+        struct Slot {
+            v4i a[2], b[2], r[2];
+        };
+        // (party, tile) of this wave's current work item, advanced without a division; parties beyond the last are clamped
+        // for the loads past the end
+        auto load_slot = [&](uint32_t pp, size_t t, int j) {
+            const size_t gi = t * 32 + c;
+            const size_t g = (size_t)(pp < (uint32_t)a.parties ? pp : (uint32_t)a.parties - 1) * a.G + (gi < a.G ? gi : a.G - 1);
+            const int i = 2 * j + h < M ? 2 * j + h : M - 1;  // M odd: the last slot of the upper lanes repeats the last coefficient (unused)
+            const size_t off = (g * M + (size_t)i) * 32;
+            Slot sl;
+            sl.a[0] = *reinterpret_cast<const v4i*>(a.in + off), sl.a[1] = *reinterpret_cast<const v4i*>(a.in + off + 16);
+            sl.b[0] = *reinterpret_cast<const v4i*>(a.in_b + off), sl.b[1] = *reinterpret_cast<const v4i*>(a.in_b + off + 16);
+            sl.r[0] = *reinterpret_cast<const v4i*>(a.in_r + off), sl.r[1] = *reinterpret_cast<const v4i*>(a.in_r + off + 16);
+            return sl;
+        };
+        auto elem = [](const v4i (&w)[2]) {
+            const uint32_t ww[8] = {(uint32_t)w[0][0], (uint32_t)w[0][1], (uint32_t)w[0][2], (uint32_t)w[0][3],
+                                    (uint32_t)w[1][0], (uint32_t)w[1][1], (uint32_t)w[1][2], (uint32_t)w[1][3]};
+            return F::from_words(ww);
+        };
+        // c = a b - r2t as 8 words of a value below 2 r (any representative below 2^256 serves: the table is linear in the bytes)
+        auto product = [&](const Slot& sl, v4i& lo, v4i& hi) {
+            if constexpr ((ABL & 8) != 0) {  // timing only: no field arithmetic, every load stays
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lo[k] = sl.a[0][k] ^ sl.b[0][k] ^ sl.r[0][k], hi[k] = sl.a[1][k] ^ sl.b[1][k] ^ sl.r[1][k];
+                return;
+            }
+            const F::E am = F::mulc_u(elem(sl.a), a.r2);            // a R
+            const F::E pr = F::mont(elem(sl.b), am);               // a b, < 2 r
+            const F::E cc = F::canon_loose(F::template sub<2>(pr, elem(sl.r)));
+            uint32_t w[8];
+            F::to_words(cc, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lo[k] = (int)w[k], hi[k] = (int)w[4 + k];
+        };
+        uint32_t pp = 0;
+        size_t t = (size_t)wg_in_role * WAVES + wave;
+        auto settle = [&](uint32_t& q, size_t& u) {
+            while (u >= ntiles && q < (uint32_t)a.parties) u -= ntiles, ++q;
+        };
+        settle(pp, t);
+        // slots are requested SD ahead of their use, across the item boundary: while the last slots of an item are multiplied
+        // and while its pairs run, the first SD slots of the wave's next item are on their way
+        constexpr int SD = TRIPLE_DEPTH;
+        static_assert(SD >= 1 && SD <= NS, "slot prefetch depth");
+        Slot ring[SD];
+        if (pp < (uint32_t)a.parties) {
+#pragma unroll
+            for (int j = 0; j < SD; ++j) ring[j] = load_slot(pp, t, j);
+            if constexpr (STATIC) dropped_stores();
         }
-    }
-    while (t < ntiles) {
-        if (STATIC || t + tstep < ntiles) load_inputs(t + tstep, setB);
-        process_tile(t, setA);
-        t += tstep;
-        if (t >= ntiles) break;
-        if (STATIC || t + tstep < ntiles) load_inputs(t + tstep, setA);
-        process_tile(t, setB);
-        t += tstep;
+        v4i data[M];
+        while (pp < (uint32_t)a.parties) {
+            uint32_t ppn = pp;
+            size_t tn = t + tstep;
+            settle(ppn, tn);
+            const size_t tnc = tn < ntiles ? tn : ntiles - 1;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                v4i lo, hi;
+                product(ring[j % SD], lo, hi);
+                ring[j % SD] = j + SD < NS ? load_slot(pp, t, j + SD) : load_slot(ppn, tnc, j + SD - NS);
+                // lower lanes hold coefficient 2 j, upper lanes 2 j + 1: the swap leaves (low half | high half) of 2 j in lo and
+                // of 2 j + 1 in hi, each lane with its own 16 bytes
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)lo[k], (uint32_t)hi[k], false, false);
+                    lo[k] = (int)sw[0], hi[k] = (int)sw[1];
+                }
+                data[2 * j] = flip(lo);
+                if (2 * j + 1 < M) data[2 * j + 1] = flip(hi);
+            }
+            pairs_of_tile(t, data, a.out + (size_t)pp * (size_t)a.nout * a.out_stride * 32);
+            pp = ppn, t = tn;
+        }
+    } else {
+        // the tile loop of k_mfma_rows: two input register sets, the loads of a wave's NEXT tile issued before it starts on the
+        // current one
+        v4i setA[M], setB[M];
+        size_t t = (size_t)wg_in_role * WAVES + wave;
+        if (t < ntiles) {
+            load_inputs(t, setA);
+            if constexpr (STATIC) dropped_stores();
+        }
+        while (t < ntiles) {
+            if (STATIC || t + tstep < ntiles) load_inputs(t + tstep, setB);
+            process_tile(t, setA);
+            t += tstep;
+            if (t >= ntiles) break;
+            if (STATIC || t + tstep < ntiles) load_inputs(t + tstep, setA);
+            process_tile(t, setB);
+            t += tstep;
+        }
     }
 }
 

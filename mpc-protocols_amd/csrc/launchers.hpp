@@ -75,7 +75,8 @@ bool launch_mfma_rows_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_
 bool launch_mfma_rows_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 bool launch_mfma_rows_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 bool launch_mfma_rows_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
-// the encode on a domain of roots of unity with the points taken in pairs (k, k + size / 2): half the MFMAs (kernels_mfma_bfly.hpp)
+// the encode on a domain of roots of unity with the points taken in pairs (k, k + size / 2): half the MFMAs (kernels_mfma_bfly.hpp);
+// with a.in_b set: the fused local product + encode of triple generation (one role of 8 or 16 pairs; false otherwise)
 bool launch_mfma_bfly_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 bool launch_mfma_bfly_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 bool launch_mfma_bfly_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);

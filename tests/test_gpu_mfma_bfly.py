@@ -137,3 +137,41 @@ def test_full_size_config2(eng):
     assert eng.dev_vandermonde_apply(s_in.data_ptr(), G, n, d, ysum.data_ptr(), 0) == 0
     eng.sync()
     assert torch.equal(ysum, s_out)
+
+
+@pytest.mark.parametrize("n,t,G,parties", [(16, 5, 9000 + 7, 16), (16, 5, 140000, 1), (13, 4, 50000 + 3, 3), (16, 2, 70000, 2), (16, 7, 33000 + 1, 4),
+                                           (20, 3, 44000 + 5, 3), (24, 4, 66000, 2), (9, 1, 131072, 1)])
+def test_triple_generation_encode_with_the_products_inside(eng, n, t, G, parties):
+    """hbmpc_dev_triple_encode_parties on large batches: the local products a b - r2t are computed inside the matrix-core encode
+    (k_mfma_bfly<.., TRIPLE>).  Against hbmpc_dev_triple_local + hbmpc_dev_vandermonde_apply_parties with the matrix cores off
+    (the whole array), and against the oracle on sampled chunks of the first and the last party; edge operands included"""
+    import torch
+    d = 2 * t
+    N = G * (d + 1)
+    dev = torch.device("cuda", 0)
+    ah, bh, rh = (O.fill_random(160 + k + n, parties * N) for k in range(3))
+    ah[:d + 1] = 0
+    bh[d + 1:2 * (d + 1)] = O.ints_to_u256([O_R - 1] * (d + 1))
+    ah[d + 1:2 * (d + 1)] = O.ints_to_u256([O_R - 1] * (d + 1))
+    rh[2 * (d + 1):3 * (d + 1)] = O.ints_to_u256([O_R - 1] * (d + 1))
+    a, b, r = (torch.from_numpy(v.view(np.int64)).to(dev) for v in (ah, bh, rh))
+    tmp = torch.empty((parties * N, 4), dtype=torch.int64, device=dev)
+    y1 = torch.full((parties, n, G, 4), -1, dtype=torch.int64, device=dev)
+    y2 = torch.full((parties, n, G, 4), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    eng.set_matrix_cores(1, 65536)
+    assert eng.dev_triple_encode_parties(a.data_ptr(), b.data_ptr(), r.data_ptr(), G, n, d, parties, 0, y1.data_ptr()) == 0, eng.last_error()
+    eng.set_matrix_cores(0)
+    try:
+        assert eng.dev_elem("triple_local", [a.data_ptr(), b.data_ptr(), r.data_ptr(), tmp.data_ptr()], parties * N) == 0
+        assert eng.dev_vandermonde_apply_parties(tmp.data_ptr(), G, n, d, parties, y2.data_ptr()) == 0
+        eng.sync()
+    finally:
+        eng.set_matrix_cores(1, 65536)
+    assert torch.equal(y1, y2)
+    idx = np.unique(np.concatenate([np.arange(0, 40), np.arange(G - 40, G), np.random.default_rng(n).integers(0, G, 60)]))
+    for p in (0, parties - 1):
+        sel = (p * G + idx)[:, None] * (d + 1) + np.arange(d + 1)[None, :]
+        x = O.triple_local(ah[sel.ravel()], bh[sel.ravel()], rh[sel.ravel()])[1].reshape(len(idx), d + 1, 4)
+        rc, want = O.vandermonde_apply(x, n, d)
+        assert rc == 0 and np.array_equal(y1[p][:, torch.as_tensor(idx, device=dev)].cpu().numpy().view(np.uint64), want), p

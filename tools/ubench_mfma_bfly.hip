@@ -68,6 +68,105 @@ static void launch_bfly(mf::MfmaRowsArgs a, int pairs, int wgs_per_cu) {
     hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
+// the fused local product + encode of triple generation: y[P][n][G] from a, b, r2t [P][G][M]
+template <int M, int WAVES, int NP, int ABL = 0, int SD = 1>
+static void launch_triple(mf::MfmaRowsArgs a, int pairs) {
+    constexpr int ROWB = M * 1024 + 256;
+    if (!mf::mf_plan_pairs(pairs, (160 * 1024) / ROWB, g_nwg, &a)) exit(3);
+    const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
+    if (mf::mf_max_role_rows(a) != NP || a.nroles != 1) exit(4);
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, ABL, true, SD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, ABL, true, SD>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+}
+template <int M, int NP>
+static int run_triple(int n, size_t G, int P, int reps) {
+    const size_t size = domain_size(n), half = size / 2;
+    std::vector<HFr> el = domain_elements<HFr>(n, n);
+    std::vector<std::vector<HFr>> V(n, std::vector<HFr>(M));
+    for (int j = 0; j < n; ++j) {
+        HFr p = HFr::one();
+        for (int k = 0; k < M; ++k) V[j][k] = p, p = p * el[j];
+    }
+    const auto tb = build_mfma_bfly_table(V, M, half);
+    uint8_t *d_tb, *d_a, *d_b, *d_r, *d_y;
+    CK(hipMalloc(&d_tb, tb.size() * 4));
+    CK(hipMemcpy(d_tb, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
+    const size_t N = (size_t)P * G * M;
+    std::vector<uint64_t> av(N * 4), bv(N * 4), rv(N * 4);
+    for (size_t i = 0; i < N; ++i) rand_canon(&av[4 * i]), rand_canon(&bv[4 * i]), rand_canon(&rv[4 * i]);
+    {
+        const uint64_t rm1[4] = {HFr::MOD[0] - 1, HFr::MOD[1], HFr::MOD[2], HFr::MOD[3]};
+        for (int i = 0; i < M; ++i)
+            for (int k = 0; k < 4; ++k) {
+                av[(0 * M + i) * 4 + k] = 0, rv[(0 * M + i) * 4 + k] = rm1[k];                  // 0 * b - (r - 1) = 1
+                av[(1 * M + i) * 4 + k] = rm1[k], bv[(1 * M + i) * 4 + k] = rm1[k], rv[(1 * M + i) * 4 + k] = 0;  // (-1)(-1) - 0
+                av[(2 * M + i) * 4 + k] = rm1[k], bv[(2 * M + i) * 4 + k] = k == 0, rv[(2 * M + i) * 4 + k] = rm1[k];  // 0
+            }
+    }
+    CK(hipMalloc(&d_a, N * 32)); CK(hipMalloc(&d_b, N * 32)); CK(hipMalloc(&d_r, N * 32));
+    CK(hipMalloc(&d_y, (size_t)P * n * G * 32));
+    CK(hipMemcpy(d_a, av.data(), N * 32, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_b, bv.data(), N * 32, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_r, rv.data(), N * 32, hipMemcpyHostToDevice));
+    CK(hipMemset(d_y, 0xee, (size_t)P * n * G * 32));
+    mf::MfmaRowsArgs a = {};
+    a.in = d_a, a.in_b = d_b, a.in_r = d_r, a.parties = P, a.G = G, a.in_chunk_major = 1, a.nv = 0, a.out = d_y, a.out_party_major = 1, a.out_stride = G;
+    a.table = d_tb, a.half = (int)half, a.nout = n;
+    {
+        HFr r2 = HFr::one();
+        const HFr two = HFr::from_u64(2);
+        for (int i = 0; i < 2 * 261; ++i) r2 = r2 * two;  // R^2, R = 2^261
+        uint64_t c[4];
+        r2.to_canon(c);
+        uint32_t w[8];
+        for (int k = 0; k < 4; ++k) w[2 * k] = (uint32_t)c[k], w[2 * k + 1] = (uint32_t)(c[k] >> 32);
+        for (int i = 0; i < 9; ++i) {  // 29-bit limbs
+            const int o = 29 * i, q = o >> 5, sft = o & 31;
+            uint32_t v = w[q] >> sft;
+            if (sft > 3 && q + 1 < 8) v |= w[q + 1] << (32 - sft);
+            a.r2[i] = v & 0x1fffffffu;
+        }
+    }
+    launch_triple<M, 8, NP>(a, (int)half);
+    CK(hipDeviceSynchronize());
+    std::vector<uint64_t> y((size_t)P * n * G * 4);
+    CK(hipMemcpy(y.data(), d_y, y.size() * 8, hipMemcpyDeviceToHost));
+    int errors = 0;
+    for (size_t s = 0; s < 96; ++s) {
+        const size_t pp = s % P, g = s < 8 ? s / 2 : (s < 16 ? G - 1 - s : rng() % G);
+        for (int j = 0; j < n; ++j) {
+            HFr acc = HFr::zero();
+            for (int k = 0; k < M; ++k) {
+                const size_t e = ((pp * G + g) * M + k) * 4;
+                acc = acc + V[j][k] * (HFr::from_canon(&av[e]) * HFr::from_canon(&bv[e]) - HFr::from_canon(&rv[e]));
+            }
+            uint64_t w[4];
+            acc.to_canon(w);
+            for (int k = 0; k < 4; ++k) errors += w[k] != y[((pp * n + j) * G + g) * 4 + k];
+        }
+    }
+    const float t8 = time_ms([&] { launch_triple<M, 8, NP>(a, (int)half); }, reps);
+    const float t12 = time_ms([&] { launch_triple<M, 12, NP>(a, (int)half); }, reps);
+    const float d2_12 = time_ms([&] { launch_triple<M, 12, NP, 0, 2>(a, (int)half); }, reps);
+    const float d2_8 = time_ms([&] { launch_triple<M, 8, NP, 0, 2>(a, (int)half); }, reps);
+    const float d3_8 = time_ms([&] { launch_triple<M, 8, NP, 0, 3>(a, (int)half); }, reps);
+    printf("slots requested 2 ahead: 12 waves %.4f ms, 8 waves %.4f; 3 ahead, 8 waves %.4f\n", d2_12, d2_8, d3_8);
+    const double bytes = (double)P * G * (3 * M + n) * 32;
+    printf("fused local product + encode, n=%d m=%d, %d parties x %zu chunks: host check of sampled chunks: %d errors; 8 waves %.4f ms (%.2f TB/s), 12 waves %.4f ms (%.2f TB/s)\n",
+           n, M, P, G, errors, t8, bytes / t8 / 1e9, t12, bytes / t12 / 1e9);
+#ifdef BFLY_ABLATE
+    if (G > 100000) {
+        const float a3 = time_ms([&] { launch_triple<M, 12, NP, 3>(a, (int)half); }, reps);
+        const float a8 = time_ms([&] { launch_triple<M, 12, NP, 8>(a, (int)half); }, reps);
+        const float a11 = time_ms([&] { launch_triple<M, 12, NP, 11>(a, (int)half); }, reps);
+        printf("   12 waves: products only (no MFMA, no epilogue arithmetic) %.4f ms | no products %.4f | loads and stores only %.4f\n", a3, a8, a11);
+    }
+#endif
+    CK(hipFree(d_tb)); CK(hipFree(d_a)); CK(hipFree(d_b)); CK(hipFree(d_r)); CK(hipFree(d_y));
+    return errors;
+}
+
 template <int M, int WP, int NRP, int NP>
 static int run(const char* name, int n, size_t G, int reps) {
     const size_t size = domain_size(n), half = size / 2;
@@ -167,6 +266,13 @@ int main(int argc, char** argv) {
     if (argc > 3) g_nwg = atoi(argv[3]);
     const size_t G = (size_t)1 << lg;
     int bad = 0;
+    if (argc > 4) {  // config 4's shape: 16 parties x 381 300 chunks of 11 (4 194 300 triples per party)
+        bad += run_triple<11, 8>(16, 1000 + 13, 3, 2);
+        bad += run_triple<11, 8>(16, 381300, atoi(argv[4]), reps);
+        bad += run_triple<6, 8>(16, 381300, atoi(argv[4]), reps);
+        printf(bad ? "FAILED\n" : "ok\n");
+        return bad != 0;
+    }
     bad += run<6, 16, 0, 8>("config 2 (n = 16, t = 5)", 16, G, reps);
     bad += run<11, 12, 11, 8>("config 3 (n = 31, t = 10)", 31, G, reps);
     bad += run<3, 16, 0, 4>("n = 7, t = 2", 7, G, reps);
