@@ -705,10 +705,10 @@ def bench_pipeline(ctx):
         G = N // m
         dom = lambda: eng.dev_triple_encode_parties(tg.a, tg.b, tg.r2t, G, n, d2, n, tg.c, tg.Y, stream)
         dom_bytes = n * (3 * N + n * G) * 32          # per party: a, b, r2t read, Y[party][n][G] written
-        dom_name = "k_mfma_bfly<11,12,8,TRIPLE>"     # the local products inside the matrix-core encode (kernels_mfma_bfly.hpp)
+        dom_name = "k_mfma_bfly<11,8,8,TRIPLE,2>"     # the local products inside the matrix-core encode (kernels_mfma_bfly.hpp)
         step_bytes = dom_bytes + (n * n * G + n * G) * 32 + (n * G + N) * 32 + n * N * 64 + N * 32
         tkey = f"triple_encode_parties_n{n}_t{t}_N{N}"
-        limiter = ("vector issue at the sustained clock as much as HBM: 22 Montgomery products per chunk of 11 triples (a R, then a b) + 16 "
+        limiter = ("vector issue at the sustained clock as much as HBM: 11 lazy products + Montgomery reductions per chunk of 11 triples and 16 "
                    "carry / reduction epilogues; the same launch with loads and stores only takes 1.92 ms (5.0 TB/s), "
                    "profiles/r03_mfma_bfly_triple.txt")
     else:

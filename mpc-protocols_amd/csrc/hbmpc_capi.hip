@@ -1197,8 +1197,8 @@ static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const voi
     // generation 0.043 ms against 0.057 ms
     const bool small_two = tmp && G * parties <= ctx->wide_max_chunks / 4;
     // Large batches on 9 .. 32 points: the products are computed inside the matrix-core encode with the points in pairs
-    // (k_mfma_bfly<.., TRIPLE>, kernels_mfma_bfly.hpp) -- config 4's 16 parties x 381 300 chunks: 2.35 - 2.45 ms against
-    // 2.55 - 2.65 of the fused FFT kernel (profiles/r03_mfma_bfly_triple.txt)
+    // (k_mfma_bfly<.., TRIPLE>, kernels_mfma_bfly.hpp) -- config 4's 16 parties x 381 300 chunks: 2.22 - 2.28 ms against
+    // 2.53 - 2.55 of the fused FFT kernel on the same box (profiles/r03_mfma_bfly_triple.txt)
     if (ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && dp1 >= 2 && dp1 <= MF_MAX_M && size >= 16 &&
         size <= 32 && n > size / 2 && G * parties >= ((size_t)1 << 17) && G * dp1 * 32 < ((size_t)1 << 32) && parties <= 65535) {
         const size_t half = size / 2;
@@ -1207,22 +1207,24 @@ static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const voi
         const int nwg = ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus;
         if (half * mf_bfly_row_bytes(dp1) <= 160 * 1024 && mf::mf_plan_pairs((int)half, (int)half, nwg, &ma)) {
             const uint32_t* tab;
-            ShareErrorCode rc = get_table(ctx, key("mfbfly", {n, dp1}, ctx->impl), [&] {
+            // rows alpha_j^i R, R = 2^261: the kernel hands over (a b - r2t) / R (one Montgomery reduction, no conversions)
+            ShareErrorCode rc = get_table(ctx, key("mfbflyR", {n, dp1}, ctx->impl), [&] {
                 std::vector<HFr> el = domain_elements<HFr>(n, n);
+                HFr R = HFr::one();
+                const HFr two = HFr::from_u64(2);
+                for (int i = 0; i < 261; ++i) R = R * two;
                 std::vector<std::vector<HFr>> V(n, std::vector<HFr>(dp1));
                 for (size_t j = 0; j < n; ++j) {
-                    HFr p = HFr::one();
+                    HFr p = R;
                     for (size_t k = 0; k < dp1; ++k) V[j][k] = p, p = p * el[j];
                 }
                 return build_mfma_bfly_table(V, dp1, half);
             }, &tab);
             if (rc != ShareSuccess) return rc;
-            const ElemConsts cs = elem_consts(ctx->impl);
             ma.in = (const uint8_t*)a, ma.in_b = (const uint8_t*)b, ma.in_r = (const uint8_t*)r2t;
             ma.parties = (int)parties, ma.G = G, ma.in_chunk_major = 1, ma.nv = 0;
             ma.table = (const uint8_t*)tab, ma.half = (int)half, ma.nout = (int)n;
             ma.out = (uint8_t*)y, ma.out_party_major = 1, ma.out_stride = G;
-            for (int i = 0; i < 9; ++i) ma.r2[i] = cs.r2[i];
             const int mi = (int)dp1;
             if (launch_mfma_bfly_a(mi, ma, ctx->device, s) || launch_mfma_bfly_b(mi, ma, ctx->device, s) ||
                 launch_mfma_bfly_c(mi, ma, ctx->device, s) || launch_mfma_bfly_d(mi, ma, ctx->device, s)) {

@@ -357,11 +357,11 @@ struct MfmaRowsArgs {
     int direct;           // 1 (decode, ONE role): no OEC round exists, a chunk that fails the verification fails for good and this
                           // kernel is the whole call (kernels_recover.hpp: fail_chunk / count_failures / finish_direct)
     int half, nout;       // kernels_mfma_bfly.hpp only: table rows are point PAIRS (k, k + half), outputs k + half >= nout do not exist
-    // k_mfma_bfly<.., TRIPLE>: the inputs are a b - r2t of `in` (a), in_b and in_r, x[parties][G][M] each; r2 = R^2 mod r (ElemConsts::r2)
+    // k_mfma_bfly<.., TRIPLE>: the inputs are (a b - r2t) / 2^261 of `in` (a), in_b and in_r, x[parties][G][M] each, and the
+    // table rows carry the factor 2^261
     const uint8_t* in_b;
     const uint8_t* in_r;
     int parties;
-    uint32_t r2[9];
 };
 
 // NR > 0: every role of the launch has at most NR rows and the row loop is unrolled NR times with a compile-time trip

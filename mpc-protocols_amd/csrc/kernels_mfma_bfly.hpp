@@ -28,8 +28,8 @@ constexpr int MF_BFLY_BIAS = 256;
 // (the stores stay), 2 = no MFMAs, 4 = no LDS operand reads either, 8 = (TRIPLE) no field products
 // TRIPLE: the encode of triple generation -- the inputs are the local products c = a b - r2t of three arrays (triple_gen,
 // honeybadger/triple_gen/mod.rs:181-260: the shares of a b are masked with the degree-2t randomness before they are opened),
-// computed in this kernel: lane (chunk, h) multiplies the coefficients of its chunk whose index has parity h (Montgomery,
-// fr_u29.hpp) and one v_permlane32_swap per word hands the halves round so that every lane ends up with its 16 bytes of every
+// computed in this kernel: lane (chunk, h) multiplies the coefficients of its chunk whose index has parity h (one lazy product
+// and one Montgomery reduction each, fr_u29.hpp) and one v_permlane32_swap per word hands the halves round so that every lane ends up with its 16 bytes of every
 // coefficient -- the B operands, without a trip through memory or the LDS.  The tile index then runs over parties x tiles
 // (x[P][G][M] -> y[P][n][G]).
 template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1>
@@ -183,16 +183,24 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                                     (uint32_t)w[1][0], (uint32_t)w[1][1], (uint32_t)w[1][2], (uint32_t)w[1][3]};
             return F::from_words(ww);
         };
-        // c = a b - r2t as 8 words of a value below 2 r (any representative below 2^256 serves: the table is linear in the bytes)
+        // x = (a b - r2t) R^-1 (R = 2^261, the Montgomery radix of fr_u29.hpp) as 8 words of a value below 2 r -- any
+        // representative below 2^256 serves, the table is linear in the bytes -- from ONE reduction: the 81 limb products of
+        // a b and the limbs of 2 r - r2t go into the same 18 columns (U_SUBC2 keeps every limb difference non-negative), then
+        // the 72 multiply-adds of the Montgomery reduction.  The factor R^-1 is undone by the TABLE, whose rows are
+        // alpha^i R for this kernel (hbmpc_capi.hip: "mfbflyR"), so no operand is ever converted to Montgomery form.
         auto product = [&](const Slot& sl, v4i& lo, v4i& hi) {
             if constexpr ((ABL & 8) != 0) {  // timing only: no field arithmetic, every load stays
 #pragma unroll
                 for (int k = 0; k < 4; ++k) lo[k] = sl.a[0][k] ^ sl.b[0][k] ^ sl.r[0][k], hi[k] = sl.a[1][k] ^ sl.b[1][k] ^ sl.r[1][k];
                 return;
             }
-            const F::E am = F::mulc_u(elem(sl.a), a.r2);            // a R
-            const F::E pr = F::mont(elem(sl.b), am);               // a b, < 2 r
-            const F::E cc = F::canon_loose(F::template sub<2>(pr, elem(sl.r)));
+            const F::E ea = elem(sl.a), eb = elem(sl.b), er = elem(sl.r);
+            F::Acc A;
+            F::acc_zero(A);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A.c[i] += (uint64_t)(consts::U_SUBC2[i] - er.l[i]);
+            F::acc_mac_pinned(A, ea, eb.l);
+            const F::E cc = F::canon_loose(F::acc_reduce(A));
             uint32_t w[8];
             F::to_words(cc, w);
 #pragma unroll
@@ -220,20 +228,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
             size_t tn = t + tstep;
             settle(ppn, tn);
             const size_t tnc = tn < ntiles ? tn : ntiles - 1;
+            // positions 0 .. NSP - 1, NSP = the slot count rounded up to the ring size: a slot always returns to the ring entry
+            // it had in the previous item (positions >= NS are empty: nothing is multiplied, nothing requested for them)
+            constexpr int NSP = (NS + SD - 1) / SD * SD;
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
+            for (int j = 0; j < NSP; ++j) {
                 v4i lo, hi;
-                product(ring[j % SD], lo, hi);
-                ring[j % SD] = j + SD < NS ? load_slot(pp, t, j + SD) : load_slot(ppn, tnc, j + SD - NS);
-                // lower lanes hold coefficient 2 j, upper lanes 2 j + 1: the swap leaves (low half | high half) of 2 j in lo and
-                // of 2 j + 1 in hi, each lane with its own 16 bytes
+                if (j < NS) product(ring[j % SD], lo, hi);
+                if (j + SD < NS) ring[j % SD] = load_slot(pp, t, j + SD);
+                else if (j + SD >= NSP) ring[j % SD] = load_slot(ppn, tnc, j + SD - NSP);
+                if (j < NS) {
+                    // lower lanes hold coefficient 2 j, upper lanes 2 j + 1: the swap leaves (low half | high half) of 2 j in lo
+                    // and of 2 j + 1 in hi, each lane with its own 16 bytes
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)lo[k], (uint32_t)hi[k], false, false);
-                    lo[k] = (int)sw[0], hi[k] = (int)sw[1];
+                    for (int k = 0; k < 4; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)lo[k], (uint32_t)hi[k], false, false);
+                        lo[k] = (int)sw[0], hi[k] = (int)sw[1];
+                    }
+                    data[2 * j] = flip(lo);
+                    if (2 * j + 1 < M) data[2 * j + 1] = flip(hi);
                 }
-                data[2 * j] = flip(lo);
-                if (2 * j + 1 < M) data[2 * j + 1] = flip(hi);
             }
             pairs_of_tile(t, data, a.out + (size_t)pp * (size_t)a.nout * a.out_stride * 32);
             pp = ppn, t = tn;

@@ -88,7 +88,15 @@ static int run_triple(int n, size_t G, int P, int reps) {
         HFr p = HFr::one();
         for (int k = 0; k < M; ++k) V[j][k] = p, p = p * el[j];
     }
-    const auto tb = build_mfma_bfly_table(V, M, half);
+    std::vector<std::vector<HFr>> VR = V;  // the kernel hands over (a b - r2t) / R: the table rows carry R = 2^261
+    {
+        HFr R = HFr::one();
+        const HFr two = HFr::from_u64(2);
+        for (int i = 0; i < 261; ++i) R = R * two;
+        for (auto& row : VR)
+            for (auto& v : row) v = v * R;
+    }
+    const auto tb = build_mfma_bfly_table(VR, M, half);
     uint8_t *d_tb, *d_a, *d_b, *d_r, *d_y;
     CK(hipMalloc(&d_tb, tb.size() * 4));
     CK(hipMemcpy(d_tb, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
@@ -113,21 +121,6 @@ static int run_triple(int n, size_t G, int P, int reps) {
     mf::MfmaRowsArgs a = {};
     a.in = d_a, a.in_b = d_b, a.in_r = d_r, a.parties = P, a.G = G, a.in_chunk_major = 1, a.nv = 0, a.out = d_y, a.out_party_major = 1, a.out_stride = G;
     a.table = d_tb, a.half = (int)half, a.nout = n;
-    {
-        HFr r2 = HFr::one();
-        const HFr two = HFr::from_u64(2);
-        for (int i = 0; i < 2 * 261; ++i) r2 = r2 * two;  // R^2, R = 2^261
-        uint64_t c[4];
-        r2.to_canon(c);
-        uint32_t w[8];
-        for (int k = 0; k < 4; ++k) w[2 * k] = (uint32_t)c[k], w[2 * k + 1] = (uint32_t)(c[k] >> 32);
-        for (int i = 0; i < 9; ++i) {  // 29-bit limbs
-            const int o = 29 * i, q = o >> 5, sft = o & 31;
-            uint32_t v = w[q] >> sft;
-            if (sft > 3 && q + 1 < 8) v |= w[q + 1] << (32 - sft);
-            a.r2[i] = v & 0x1fffffffu;
-        }
-    }
     launch_triple<M, 8, NP>(a, (int)half);
     CK(hipDeviceSynchronize());
     std::vector<uint64_t> y((size_t)P * n * G * 4);
