@@ -416,6 +416,19 @@ ShareErrorCode hbmpc_dev_pack_fvec(hbmpc_ctx* ctx, const U256* rows_dev, size_t 
 ShareErrorCode hbmpc_dev_unpack_fvec(hbmpc_ctx* ctx, const void* payloads_dev, size_t payload_stride_bytes,
                                      size_t payload_bytes, size_t G, size_t n_rows, U256* rows_dev, size_t row_stride,
                                      uint32_t* status_dev, void* stream);
+/* apply_vandermonde with the input given as d + 1 ROWS: row i = coefficient i of all G chunks, x_row_stride elements apart
+ * (x_row_stride >= G).  This is the shape of the preprocessing producers' mixing step (share_gen.rs:150-175,
+ * ran_dou_sha/mod.rs:270-312: every recipient multiplies the n shares it was dealt by make_vandermonde(n, n - 1)): with all
+ * parties' buffers on one device the share of dealer p for (recipient, element) is row p of the dealt array, so the n x n
+ * map reads the dealers' outputs where they lie -- y[i][g] = sum_p alpha_i^p x[p][g] -- and the [recipient][element][dealer]
+ * copy is never made.  Large Fr batches with 2 <= d + 1 <= 16 on domains of 8 .. 256 points run on the matrix cores straight
+ * from the rows (csrc/kernels_mfma_bfly.hpp); every other shape transposes into tmp_dev (G * (d + 1) elements; may be null
+ * when the direct kernel covers the shape -- a call that needs it and has none fails with InvalidInput) and takes the
+ * chunk-major encode.  Output as hbmpc_dev_vandermonde_apply: y[n][G]. */
+ShareErrorCode hbmpc_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                size_t d, U256* tmp_dev, U256* y_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                   size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, void* stream);
 /* In-place wire path -- no pack / unpack pass.  A payload that starts 8 bytes before a 32-byte boundary has its
  * elements 32-byte aligned, so the encode kernel writes the payload bodies itself and the decode reads them where
  * they arrived:

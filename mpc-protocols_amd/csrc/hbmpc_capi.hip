@@ -557,8 +557,9 @@ extern "C" void hbmpc_graph_destroy(hbmpc_graph* graph) {
 
 // ---- a3 / a5: evaluation on the domain ---------------------------------------------------------
 // apply_vandermonde / compute_shares as int8 MFMA tiles (kernels_mfma.hpp): row j of the table is (alpha_j^k)_k
+// x_row_stride != 0: x is given as d + 1 ROWS of G elements, x_row_stride elements apart (the point-pair kernel only)
 static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t dp1, EvalOut y, hipStream_t s,
-                          ShareErrorCode* rc_out) {
+                          ShareErrorCode* rc_out, size_t x_row_stride = 0) {
     *rc_out = ShareSuccess;
     const size_t rowb = mf_row_bytes(dp1);
     mf::MfmaRowsArgs a;
@@ -567,8 +568,8 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
     const int nwg = ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus;
     // (measured, 4 096 .. 16 384 chunks: n = 20, d = 6: 6.7 .. 10.0 us against 19 .. 20; n = 31, d = 10 -- three roles --
     // 9.8 and 15.1 us against 17.6 and 18.2 at 4 096 and 8 192 chunks, behind at 16 384)
-    bool team = ctx->mfma_team && (G + 31) / 32 <= (size_t)nwg * 2;
-    bool plain_ok = mf::mf_plan_roles((int)n, 0, (int)((160 * 1024 - (team ? 128 : 0)) / rowb), nwg, &a);
+    bool team = ctx->mfma_team && x_row_stride == 0 && dp1 <= MF_MAX_M && (G + 31) / 32 <= (size_t)nwg * 2;
+    bool plain_ok = x_row_stride == 0 && dp1 <= MF_MAX_M && mf::mf_plan_roles((int)n, 0, (int)((160 * 1024 - (team ? 128 : 0)) / rowb), nwg, &a);
     if (plain_ok && team && a.nroles > 1 && (G + 31) / 32 > (size_t)nwg) {
         team = false;
         plain_ok = mf::mf_plan_roles((int)n, 0, (int)((160 * 1024) / rowb), nwg, &a);
@@ -600,11 +601,20 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
         mf::MfmaRowsArgs b = a;
         if (mf::mf_plan_pairs((int)half, (int)((160 * 1024) / mf_bfly_row_bytes(dp1)), nwg, &b)) {
             const uint32_t* tab;
-            *rc_out = get_table(ctx, key("mfbfly", {n, dp1}, ctx->impl), [&] { return build_mfma_bfly_table(vandermonde(), dp1, half); }, &tab);
+            std::array<size_t, 5> aux = {0, 0, 0, 0, 0};  // aux[0]: the table's words (0: its digit-sum bound does not hold, tables_mfma.hpp)
+            *rc_out = get_table(ctx, key("mfbfly", {n, dp1}, ctx->impl), [&] {
+                std::vector<uint32_t> tbl = build_mfma_bfly_table(vandermonde(), dp1, half);
+                aux[0] = tbl.size();
+                return tbl;
+            }, &tab, &aux);
             if (*rc_out != ShareSuccess) return true;
+            bool ok = aux[0] != 0;
             b.table = (const uint8_t*)tab;
             b.half = (int)half, b.nout = (int)n;
-            bool ok = true;
+            if (x_row_stride) {
+                b.in_chunk_major = 0, b.row_stride = x_row_stride;
+                for (size_t i = 0; i < dp1; ++i) b.rows.set(i, (unsigned)i);
+            }
             for (unsigned p = 0; p < y.parties && ok; ++p) {  // party-batched calls: one launch per party
                 b.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
                 b.out = (uint8_t*)y.y + (size_t)p * n * b.out_stride * 32;
@@ -692,7 +702,7 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
         return rc_mf;
     // large batches on small domains: with the points taken in pairs the matrix-core encode is ahead of the single-pass FFT
     if (impl == IMPL_U29 && size <= 16 && size >= 8 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && y.parties <= 64 &&
-        dp1 >= 2 && dp1 <= MF_MAX_M && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
+        dp1 >= 2 && dp1 <= MF_BFLY_MAX_M && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
         G * std::max(dp1, (size_t)1) * 32 < ((size_t)1 << 32) && try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf))
         return rc_mf;
     if ((impl == IMPL_U29 || gold) && size <= 16 && !ctx->force_generic) {
@@ -707,8 +717,8 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
                            : (launch_fft1_16a(c, x, G, nn, tw, y, s) || launch_fft1_16b(c, x, G, nn, tw, y, s) ||
                               launch_fft1_16c(c, x, G, nn, tw, y, s) || launch_fft1_16d(c, x, G, nn, tw, y, s))))
             return ShareSuccess;
-    } else if (impl == IMPL_U29 && ctx->matrix_cores && !ctx->force_generic && y.parties <= 64 && dp1 >= 2 && dp1 <= MF_MAX_M &&
-               G >= ctx->mfma_min_encode && G * dp1 * 32 < ((size_t)1 << 32) && n <= 255 &&
+    } else if (impl == IMPL_U29 && ctx->matrix_cores && !ctx->force_generic && y.parties <= 64 && dp1 >= 2 &&
+               dp1 <= (ctx->mfma_bfly ? MF_BFLY_MAX_M : MF_MAX_M) && G >= ctx->mfma_min_encode && G * dp1 * 32 < ((size_t)1 << 32) && n <= 255 &&
                try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf)) {
         // domains beyond 16 points: the dense n x (d + 1) map on the matrix cores beats the multi-pass FFT (config 3's
         // encode: 0.45 ms against 0.62 ms); up to 16 points the single-pass FFT stays (config 2: a tie at 0.187 ms)
@@ -1572,6 +1582,44 @@ extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_strided(hbmpc_ctx* ctx,
                                                                  void* stream) {
     REQ_GL(ctx);
     return eval_dev(ctx, x_dev, G, n, d, y_out_dev, stream, 1, y_row_stride);
+}
+// x given as d + 1 rows (see include/hbmpc_hip.h): the point-pair matrix-core kernel reads them in place; every other
+// shape goes through the workspace (transpose, then the chunk-major encode)
+static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x_row_stride, size_t G, size_t n, size_t d, void* tmp,
+                                    void* y, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
+    if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
+    if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
+    if (x_row_stride < G) return fail(ctx, InvalidInput, "input row stride must be >= G");
+    if (G == 0) return ShareSuccess;
+    if (!x_rows || !y) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    const size_t size = domain_size(n), dp1 = d + 1;
+    ShareErrorCode rc_mf = ShareSuccess;
+    if (ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && dp1 >= 2 && dp1 <= MF_BFLY_MAX_M && size >= 8 &&
+        n <= 255 && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 && G * 32 < ((size_t)1 << 32) &&
+        try_mfma_eval(ctx, (const uint32_t*)x_rows, G, n, dp1, EvalOut{(uint32_t*)y, 0, 1}, s, &rc_mf, x_row_stride)) {
+        if (rc_mf != ShareSuccess) return rc_mf;
+        HIP_TRY(ctx, hipGetLastError());
+        return ShareSuccess;
+    }
+    if (!tmp) return fail(ctx, InvalidInput, "no kernel reads this shape from rows: pass a workspace of G * (d + 1) elements");
+    if ((dp1 + 15) / 16 > 65535) return fail(ctx, InvalidInput, "d beyond the launch grid");
+    launch_transpose(is_gold(ctx) ? 1 : 4, (const uint64_t*)x_rows, dp1, G, x_row_stride, (uint64_t*)tmp, dp1, 1, 0, 0, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return eval_dev(ctx, tmp, G, n, d, y, stream);
+}
+extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                           size_t d, U256* tmp_dev, U256* y_out_dev, void* stream) {
+    REQ_FR(ctx);
+    return eval_rows_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, stream);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G,
+                                                              size_t n, size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, void* stream) {
+    REQ_GL(ctx);
+    return eval_rows_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, stream);
 }
 static ShareErrorCode encode_fvec_any(hbmpc_ctx* ctx, const void* x_dev, size_t G, size_t n, size_t d, void* payloads_dev,
                                       size_t payload_stride_bytes, void* stream) {

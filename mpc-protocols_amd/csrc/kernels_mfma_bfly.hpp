@@ -34,7 +34,7 @@ constexpr int MF_BFLY_BIAS = 256;
 // (x[P][G][M] -> y[P][n][G]).
 template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
-    static_assert(M >= 2 && M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp)");
+    static_assert(M >= 2 && M <= 16, "digit sums must stay below 0xff0000 (tables_mfma.hpp: proved per table for M = 16)");
     constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
     constexpr int NT = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];  // role.nrows * ROWB
@@ -63,11 +63,21 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     // vmcnt retires in order: with a conditional load or store in between, the wait for the OLDER input set also drains
     // the set requested a moment ago, i.e. every other tile would pay a full HBM round trip.
     constexpr bool STATIC = NP > 0;
+    // inputs: chunk-major x[G][M] (compute_shares, apply_vandermonde) or M rows, row i at in + rows[i] * row_stride * 32 (the
+    // producers' mixing step reads the dealt shares where the dealers' encodes left them: S[dealer][..])
     auto load_inputs = [&](size_t t, v4i (&dst)[M]) {
         const size_t gi = t * 32 + c;
         const uint32_t g = (uint32_t)(gi < a.G ? gi : a.G - 1);
 #pragma unroll
-        for (int i = 0; i < M; ++i) dst[i] = *reinterpret_cast<const v4i*>(a.in + (size_t)i * 32 + (g * (M * 32u) + 16u * h));
+        for (int i = 0; i < M; ++i) {
+            if (a.in_chunk_major) {
+                dst[i] = *reinterpret_cast<const v4i*>(a.in + (size_t)i * 32 + (g * (M * 32u) + 16u * h));
+            } else {
+                uint32_t ri = (uint32_t)a.rows[i];
+                asm volatile("" : "+s"(ri));  // recomputed at every use (scalar registers, as in k_mfma_rows)
+                dst[i] = *reinterpret_cast<const v4i*>(a.in + (size_t)ri * a.row_stride * 32 + (g * 32u + 16u * h));
+            }
+        }
     };
     const uint32_t row_bytes = (uint32_t)([&] {
         const size_t b = a.out_party_major ? a.G * 32 : a.G * a.out_stride * 32;

@@ -183,6 +183,11 @@ inline std::vector<uint32_t> build_mfma_table(const std::vector<std::vector<HFr>
 // flips digit b alone; neither changes the value mod r, and the digit sums move by at most 512 -- inside the slack the
 // bound of the plain table leaves (|s d| <= 128 * 127 on the negative side).
 constexpr size_t MF_BFLY_BIAS_BYTES = 256;
+// m = 16 is admitted for the pair tables (n x n maps on a 16-point domain: the preprocessing producers' mixing matrix and its
+// inverse): the worst-case bound above exceeds 0xff0000 by 0.4 % there, so the builder PROVES the bound for the table at hand --
+// the extremes of every digit sum over all inputs, from the table's own digits -- and returns an empty table when it does
+// not hold (the caller then takes the FFT kernels).  For m <= 15 the same proof is an internal check that cannot fail.
+constexpr size_t MF_BFLY_MAX_M = 16;
 inline size_t mf_bfly_row_bytes(size_t m) { return m * 1024 + MF_BFLY_BIAS_BYTES; }
 inline std::vector<uint32_t> build_mfma_bfly_table(const std::vector<std::vector<HFr>>& C, size_t m, size_t half) {
     const size_t n = C.size(), RB = mf_row_bytes(m), PB = mf_bfly_row_bytes(m), pairs = half < n ? half : n;
@@ -195,17 +200,33 @@ inline std::vector<uint32_t> build_mfma_bfly_table(const std::vector<std::vector
         const int32_t* b1 = reinterpret_cast<const int32_t*>(src + p * RB + m * 1024);
         int32_t* bE = reinterpret_cast<int32_t*>(dst + p * PB + m * 1024);
         int32_t* bT = bE + 32;
-        if (p + half >= n) {
-            for (int b = 0; b < 32; ++b) bE[b] = b1[b], bT[b] = 0;
-            continue;
-        }
+        const bool partner = p + half < n;
         int32_t b2[32];
-        memcpy(b2, src + (p + half) * RB + m * 1024, sizeof b2);
-        if ((b1[0] ^ b2[0]) & 1)
-            for (int b = 0; b < 32; ++b) b2[b] += (int32_t)((HFr::MOD[b >> 3] >> (8 * (b & 7))) & 0xff);
-        for (int b = 1; b < 32; ++b)
-            if ((b1[b] ^ b2[b]) & 1) b2[b] += 1, b2[b - 1] -= 256;
-        for (int b = 0; b < 32; ++b) bE[b] = (b1[b] + b2[b]) / 2, bT[b] = (b1[b] - b2[b]) / 2;
+        if (!partner) {
+            for (int b = 0; b < 32; ++b) bE[b] = b1[b], bT[b] = 0, b2[b] = b1[b];
+        } else {
+            memcpy(b2, src + (p + half) * RB + m * 1024, sizeof b2);
+            if ((b1[0] ^ b2[0]) & 1)
+                for (int b = 0; b < 32; ++b) b2[b] += (int32_t)((HFr::MOD[b >> 3] >> (8 * (b & 7))) & 0xff);
+            for (int b = 1; b < 32; ++b)
+                if ((b1[b] ^ b2[b]) & 1) b2[b] += 1, b2[b - 1] -= 256;
+            for (int b = 0; b < 32; ++b) bE[b] = (b1[b] + b2[b]) / 2, bT[b] = (b1[b] - b2[b]) / 2;
+        }
+        // the bound: data bytes are s in [-128, 127]; digit b of slab (i, a) sits at tile[(row_of_digit(b) + 32 (a >> 4)) * 16 + (a & 15)]
+        for (int b = 0; b < 32; ++b) {
+            int64_t lo[2] = {0, 0}, hi[2] = {0, 0};
+            for (size_t i = 0; i < m; ++i) {
+                const int8_t* tile = reinterpret_cast<const int8_t*>(src + p * RB + i * 1024);
+                for (int a = 0; a < 32; ++a) {
+                    const int64_t v = tile[(mf_row_of_digit(b) + 32 * (a >> 4)) * 16 + (a & 15)];
+                    lo[i & 1] += v < 0 ? 127 * v : -128 * v;
+                    hi[i & 1] += v < 0 ? -128 * v : 127 * v;
+                }
+            }
+            const int64_t plus_lo = b1[b] + lo[0] + lo[1], plus_hi = b1[b] + hi[0] + hi[1];
+            const int64_t minus_lo = b2[b] + lo[0] - hi[1], minus_hi = b2[b] + hi[0] - lo[1];
+            if (plus_lo < 0 || plus_hi >= 0xff0000 || (partner && (minus_lo < 0 || minus_hi >= 0xff0000))) return {};
+        }
     }
     return out;
 }

@@ -490,6 +490,11 @@ class Engine:
                                             C.c_void_p(rows_d), C.c_size_t(row_stride), C.c_void_p(status_d),
                                             C.c_void_p(stream))
 
+    def dev_vandermonde_apply_rows(self, x_rows_d, x_row_stride, G, n, d, tmp_d, y_d, stream=0):
+        """x as d + 1 rows of G elements (x_row_stride apart) -> y[n][G]; tmp_d: G * (d + 1) elements or 0"""
+        return self._f("dev_vandermonde_apply_rows")(self.ctx, C.c_void_p(x_rows_d), C.c_size_t(x_row_stride), C.c_size_t(G), C.c_size_t(n),
+                                                       C.c_size_t(d), C.c_void_p(tmp_d), C.c_void_p(y_d), C.c_void_p(stream))
+
     def dev_vandermonde_apply_strided(self, x_d, G, n, d, y_d, y_row_stride, stream=0):
         return self._f("dev_vandermonde_apply_strided")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
                                                         C.c_void_p(y_d), C.c_size_t(y_row_stride), C.c_void_p(stream))

@@ -75,7 +75,7 @@ static int run(size_t n, size_t d, size_t t, const std::vector<size_t>& ids) {
     }
     // the point-pair table of the matrix-core encode (tables_mfma.hpp::build_mfma_bfly_table) for y = X * V on this domain
     if constexpr (std::is_same<H, HFr>::value) {
-        if (m >= 2 && m <= MF_MAX_M && domain_size(n) >= 4) {
+        if (m >= 2 && m <= MF_BFLY_MAX_M && domain_size(n) >= 4) {
             std::vector<std::vector<HFr>> V(n, std::vector<HFr>(m));
             for (size_t j = 0; j < n; ++j) {
                 HFr p = HFr::one();
@@ -84,7 +84,7 @@ static int run(size_t n, size_t d, size_t t, const std::vector<size_t>& ids) {
             const size_t half = domain_size(n) / 2;
             const auto tab = build_mfma_bfly_table(V, m, half);
             std::printf("bfly_bytes %zu\n", tab.size() * 4);
-            if (tab.size() * 4 <= 65536) {
+            if (tab.size() * 4 <= 140000) {
                 std::printf("bfly");
                 for (uint32_t x : tab) std::printf(" %08x", x);
                 std::printf("\n");

@@ -50,7 +50,7 @@ def three_ways(eng, x, n, d):
 
 # (n, d): pairs per role / roles.  size <= 16 takes this kernel beyond the workgroup-per-tile range only (> 512 tiles)
 SHAPES = [(5, 1), (6, 2), (7, 2), (8, 3), (9, 1), (10, 3), (11, 4), (12, 5), (13, 4), (14, 6), (15, 7), (16, 5), (16, 8), (16, 10), (16, 14),
-          (17, 1), (20, 6), (24, 8), (31, 10), (31, 13), (31, 14), (32, 9), (33, 5), (40, 3), (40, 13), (63, 12), (64, 14), (64, 2), (100, 3)]
+          (16, 15), (20, 15), (31, 15), (64, 15), (17, 1), (20, 6), (24, 8), (31, 10), (31, 13), (31, 14), (32, 9), (33, 5), (40, 3), (40, 13), (63, 12), (64, 14), (64, 2), (100, 3)]
 
 
 @pytest.mark.parametrize("n,d", SHAPES)
@@ -175,3 +175,32 @@ def test_triple_generation_encode_with_the_products_inside(eng, n, t, G, parties
         x = O.triple_local(ah[sel.ravel()], bh[sel.ravel()], rh[sel.ravel()])[1].reshape(len(idx), d + 1, 4)
         rc, want = O.vandermonde_apply(x, n, d)
         assert rc == 0 and np.array_equal(y1[p][:, torch.as_tensor(idx, device=dev)].cpu().numpy().view(np.uint64), want), p
+
+
+@pytest.mark.parametrize("n,d,G", [(16, 15, 20000 + 3), (16, 5, 40000), (31, 10, 17000 + 9), (13, 12, 30000 + 1), (16, 15, 700), (5, 2, 50000),
+                                   (40, 20, 20000)])
+def test_inputs_given_as_rows(eng, n, d, G):
+    """hbmpc_dev_vandermonde_apply_rows: x[d + 1][stride] instead of x[G][d + 1] -- read in place by the point-pair kernel where it
+    covers the shape (large batches, d + 1 <= 16), through the workspace otherwise (small batch, 4-point... domain, d + 1 > 16);
+    without a workspace those shapes are refused"""
+    import torch
+    dev = torch.device("cuda", 0)
+    x = polys(31 * n + d, G, d)
+    stride = G + 24
+    xr = torch.full((d + 1, stride, 4), -1, dtype=torch.int64, device=dev)
+    xr[:, :G] = torch.as_tensor(np.ascontiguousarray(x.transpose(1, 0, 2)).view(np.int64), device=dev)
+    tmp = torch.empty((G, d + 1, 4), dtype=torch.int64, device=dev)
+    y = torch.full((n, G, 4), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_vandermonde_apply_rows(xr.data_ptr(), stride, G, n, d, tmp.data_ptr(), y.data_ptr()) == 0, eng.last_error()
+    eng.sync()
+    rc0, y0 = O.vandermonde_apply(x, n, d)
+    assert rc0 == 0 and np.array_equal(y.cpu().numpy().view(np.uint64), y0)
+    direct = d + 1 <= 16 and n > 4 and (G + 31) // 32 > 512
+    y.fill_(-1)
+    rc = eng.dev_vandermonde_apply_rows(xr.data_ptr(), stride, G, n, d, 0, y.data_ptr())
+    eng.sync()
+    if direct:
+        assert rc == 0 and np.array_equal(y.cpu().numpy().view(np.uint64), y0)
+    else:
+        assert rc != 0 and "workspace" in eng.last_error()
