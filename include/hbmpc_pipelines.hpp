@@ -196,7 +196,7 @@ class FpMul : public CapturablePipeline {
 
 // What RanSha and RanDouSha share.  The dealers' polynomials are the INPUT (coefficient rows [dealer][K][deg + 1], column 0 the
 // secret: uploaded by the host or filled on the device by hbmpc_dev_fill_coeffs -- the reference draws them from each party's rng).
-// Layouts (all n parties on one device): dealt S[p][j, k] --transpose--> x[j, k][p] --n x n Vandermonde--> y[i][j, k]; what party j
+// Layouts (all n parties on one device): dealt S[p][j, k] --n x n Vandermonde over the rows p--> y[i][j, k]; what party j
 // sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied.
 class Producer : public CapturablePipeline {
   protected:
@@ -206,8 +206,9 @@ class Producer : public CapturablePipeline {
             pl_check(hbmpc_dev_compute_shares(ctx_, coeffs + p * K_ * (deg + 1), K_, n_, deg, S + p * n_ * K_, stream_), ctx_, "deal");
     }
     void mix(const U256* S, U256* x, U256* y) {
-        pl_check(hbmpc_dev_transpose(ctx_, S, n_, n_ * K_, n_ * K_, x, n_, 1, 0, 0, stream_), ctx_, "dealt shares -> recipients");
-        pl_check(hbmpc_dev_vandermonde_apply(ctx_, x, n_ * K_, n_, n_ - 1, y, stream_), ctx_, "n x n Vandermonde");
+        // the share of dealer p for (recipient, element) is row p of S: the n x n map reads the dealers' outputs in place; x is
+        // the workspace of the shapes that have to be transposed first
+        pl_check(hbmpc_dev_vandermonde_apply_rows(ctx_, S, n_ * K_, n_ * K_, n_, n_ - 1, x, y, stream_), ctx_, "n x n Vandermonde over the dealt shares");
     }
     void clear_bad(uint32_t* bad) {
         static const uint32_t init[2] = {0u, 0xffffffffu};

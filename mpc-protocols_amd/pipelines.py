@@ -212,8 +212,8 @@ class _Producer(_Capturable):
     shares it received for batch element k by the n x n Vandermonde matrix make_vandermonde(n, n - 1), row i of the
     result goes to verifier i, and the other rows are the party's output.
 
-    Layouts (elements; all n parties on one device):  dealt S[p][j, k]  --transpose-->  x[j, k][p]  --Vandermonde-->
-    y[i][j, k]; what party j sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied."""
+    Layouts (elements; all n parties on one device):  dealt S[p][j, k]  --Vandermonde over the rows p-->  y[i][j, k]; what
+    party j sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied."""
 
     def __init__(self, eng, n, t, K, stream=0):
         self.eng, self.n, self.t, self.K, self.stream = eng, n, t, K, stream
@@ -228,8 +228,9 @@ class _Producer(_Capturable):
     def _mix(self, S, x, y):
         """y[i][j, k] = sum_p alpha_i^p * S[p][j, k]: what every recipient computes from the n shares it was dealt"""
         e, n, K, s = self.eng, self.n, self.K, self.stream
-        _check(e.dev_transpose(S, n, n * K, n * K, x, n, stream=s), e, "dealt shares -> recipients")
-        _check(e.dev_vandermonde_apply(x, n * K, n, n - 1, y, s), e, "n x n Vandermonde")
+        # the share of dealer p for (recipient j, element k) is row p of S: the n x n map reads the dealers' outputs in place
+        # (hbmpc_dev_vandermonde_apply_rows; x is the workspace of the shapes that have to be transposed first)
+        _check(e.dev_vandermonde_apply_rows(S, n * K, n * K, n, n - 1, x, y, s), e, "n x n Vandermonde over the dealt shares")
 
     def _bad(self):
         b = np.zeros(2, dtype=np.uint32)

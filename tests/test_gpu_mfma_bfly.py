@@ -204,3 +204,37 @@ def test_inputs_given_as_rows(eng, n, d, G):
         assert rc == 0 and np.array_equal(y.cpu().numpy().view(np.uint64), y0)
     else:
         assert rc != 0 and "workspace" in eng.last_error()
+
+
+@pytest.mark.parametrize("n,G,stride_pad", [(16, 20000 + 5, 0), (16, 40000, 64), (8, 33000 + 1, 0)])
+def test_full_domain_interpolation_is_the_inverse_transform(eng, n, G, stride_pad):
+    """hbmpc_dev_batch_interpolate through all n shares of a full domain (the RanDouSha verifier, ran_dou_sha/mod.rs:569-602) on the
+    point-pair kernel with the inverse DFT rows: against the lane kernels (matrix cores off: the whole array) and against the
+    coefficients the shares were made from; arrival order shuffled, sender rows strided, degrees included"""
+    import torch
+    dev = torch.device("cuda", 0)
+    t = (n - 1) // 3
+    rng = np.random.default_rng(n + G)
+    ids = [int(i) for i in rng.permutation(n)]
+    stride = G + stride_pad
+    for true_deg in (t, 2 * t, n - 1):
+        co = polys(700 + true_deg + n, G, true_deg)
+        co[5, true_deg] = 0                           # a lower-degree column
+        rc, sh = O.compute_shares(co, n, true_deg)
+        assert rc == 0
+        ev = torch.full((n, stride, 4), -1, dtype=torch.int64, device=dev)
+        ev[:, :G] = torch.as_tensor(np.ascontiguousarray(sh[ids]).view(np.int64), device=dev)
+        outs = []
+        for mode in (1, 0):
+            eng.set_matrix_cores(mode)
+            c = torch.full((G, n, 4), -1, dtype=torch.int64, device=dev)
+            dg = torch.full((G,), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            assert eng.dev_batch_interpolate(ids, ev.data_ptr(), stride, G, n, c.data_ptr(), dg.data_ptr()) == 0, eng.last_error()
+            eng.sync()
+            outs.append((c.cpu().numpy().view(np.uint64), dg.cpu().numpy()))
+        eng.set_matrix_cores(1)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        got, deg = outs[0]
+        assert np.array_equal(got[:, :true_deg + 1], co) and not got[:, true_deg + 1:].any()
+        assert deg[6] == true_deg and deg[0] == 0 and deg[5] < true_deg
