@@ -32,7 +32,10 @@ constexpr int MF_BFLY_BIAS = 256;
 // and one Montgomery reduction each, fr_u29.hpp) and one v_permlane32_swap per word hands the halves round so that every lane ends up with its 16 bytes of every
 // coefficient -- the B operands, without a trip through memory or the LDS.  The tile index then runs over parties x tiles
 // (x[P][G][M] -> y[P][n][G]).
-template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1>
+// DEG: the outputs of a chunk are the coefficients of a polynomial (out chunk-major, one role) and a.ncoeffs[g] receives its
+// degree -- the index of the highest nonzero coefficient, 0 for the zero polynomial (DensePolynomial::degree(), what the
+// RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it.
+template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     static_assert(M >= 2 && M <= 16, "digit sums must stay below 0xff0000 (tables_mfma.hpp: proved per table for M = 16)");
     constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
@@ -99,6 +102,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         const bool live = gi < a.G;
         const uint32_t g = (uint32_t)(live ? gi : a.G - 1);
         const uint32_t qo = g * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
+        [[maybe_unused]] uint32_t degree = 0;
+        [[maybe_unused]] auto note_degree = [&](uint32_t k, bool exists, const uint32_t (&Rw)[4]) {
+            const uint32_t any = Rw[0] | Rw[1] | Rw[2] | Rw[3];
+            const auto both = __builtin_amdgcn_permlane32_swap(any, any, false, false);  // [0]: the low half's value, [1]: the high half's
+            if (exists && (both[0] | both[1]) != 0 && k > degree) degree = k;
+        };
 #pragma unroll
         for (int p = 0; p < (STATIC ? NP : role.nrows); ++p) {
             const uint8_t* cur = lds + (size_t)p * ROWB;
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 if (ABL & 1) Rw[0] = pe[0] + pt[1], Rw[1] = pe[2] + pt[3], Rw[2] = pe[4] + pt[5], Rw[3] = pe[6] + pt[7];
                 else reduce_words(T, Rw, H);
                 store_row(out, k32, true, live, qo, Rw);
+                if constexpr (DEG) note_degree(k32, true, Rw);
             }
             const bool partner = (int)k32 + a.half < a.nout;
             if (STATIC || partner) {
@@ -154,7 +164,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 if (ABL & 1) Rw[0] = pe[0] - pt[1], Rw[1] = pe[2] - pt[3], Rw[2] = pe[4] - pt[5], Rw[3] = pe[6] - pt[7];
                 else reduce_words(T, Rw, H);
                 store_row(out, k32 + (uint32_t)a.half, partner, live, qo, Rw);
+                if constexpr (DEG) note_degree(k32 + (uint32_t)a.half, partner, Rw);
             }
+        }
+        if constexpr (DEG) {  // one more counted store: lanes that do not write get an offset beyond the buffer
+            const size_t db = a.G * 4;
+            __builtin_amdgcn_raw_buffer_store_b32(degree, rt_rsrc(a.ncoeffs, (uint32_t)(db < 0xffffffe0ull ? db : 0xffffffe0ull)),
+                                                  (int)(live && h == 0 ? g * 4u : RT_OOB), 0, 0);
         }
     };
     auto process_tile = [&](size_t t, v4i (&data)[M]) {
@@ -167,7 +183,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         // as on the back edge (hipcc merges the two states to the stricter wait)
         const v4i z = {0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < 2 * NP; ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rt_rsrc(a.out, 0u), (int)RT_OOB, 0, 0);
+        for (int k = 0; k < 2 * NP + (DEG ? 1 : 0); ++k) __builtin_amdgcn_raw_buffer_store_b128(z, rt_rsrc(a.out, 0u), (int)RT_OOB, 0, 0);
     };
     if constexpr (TRIPLE) {
         using F = U29;
