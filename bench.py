@@ -738,8 +738,7 @@ def bench_pipeline(ctx):
         out["roofline"]["traffic"] = trec["hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = trec["source"]
     if pre is not None:
-        # the producers alone (their share of the step), and their compulsory traffic: deal (coefficients in, n^2 K shares out),
-        # transpose + n x n Vandermonde (n^2 K in and out, each), the verifiers' reads, the output slices
+        # the producers alone (their share of the step), and their compulsory traffic
         def ev_ms(fn):
             a0, a1, r = ctx["events"]()
             fn()
@@ -751,8 +750,10 @@ def bench_pipeline(ctx):
             torch.cuda.synchronize()
             return a0.elapsed_time(a1) / args.steps
         Krs, Krd = pre.K_rs, pre.K_rd
-        rs_b = (n * Krs * (t + 1) + 5 * n * n * Krs + 2 * t * ((2 * t + 1) * Krs + Krs * (t + 1)) + 2 * n * (n - 2 * t) * Krs) * 32
-        rd_b = (n * Krd * (3 * t + 2) + 10 * n * n * Krd + (n - t - 1) * 4 * n * Krd + 4 * n * (t + 1) * Krd) * 32
+        # deal: coefficients in, n^2 K shares out; mix: n^2 K in (the dealt rows, read in place), n^2 K out; verifiers: their
+        # sender rows in, polynomials out; output slices in and out
+        rs_b = (n * Krs * (t + 1) + 3 * n * n * Krs + 2 * t * ((2 * t + 1) * Krs + Krs * (t + 1)) + 2 * n * (n - 2 * t) * Krs) * 32
+        rd_b = (n * Krd * (3 * t + 2) + 6 * n * n * Krd + (n - t - 1) * 4 * n * Krd + 4 * n * (t + 1) * Krd) * 32
         rs_ms, rd_ms = ev_ms(lambda: pre.rs.run(check=False)), ev_ms(lambda: pre.rd.run(check=False))
         out["producers"] = {"ransha_ms": rs_ms, "ransha_algorithmic_bytes": rs_b, "ransha_GBps": rs_b / rs_ms / 1e6,
                             "randousha_ms": rd_ms, "randousha_algorithmic_bytes": rd_b, "randousha_GBps": rd_b / rd_ms / 1e6,
