@@ -210,6 +210,15 @@ class Producer : public CapturablePipeline {
         // the workspace of the shapes that have to be transposed first
         pl_check(hbmpc_dev_vandermonde_apply_rows(ctx_, S, n_ * K_, n_ * K_, n_, n_ - 1, x, y, stream_), ctx_, "n x n Vandermonde over the dealt shares");
     }
+  public:
+    // where a slice of every party's output list goes instead of the producer's own buffer: batch elements [k0, k0 + count)
+    // of party p to dst + p * stride
+    struct Slice {
+        U256* dst;
+        size_t stride, k0, count;
+    };
+
+  protected:
     void clear_bad(uint32_t* bad) {
         static const uint32_t init[2] = {0u, 0xffffffffu};
         pl_check(hbmpc_memcpy_h2d(ctx_, bad, init, sizeof init, stream_), ctx_, "h2d");
@@ -245,8 +254,8 @@ class RanSha : public Producer {
         for (size_t i = 0; i < verify_senders; ++i) ids_.push_back(i);
     }
     void deal() { Producer::deal(coeffs, t_, S); }
-    // everything after the dealers' messages have arrived
-    void finish() {
+    // everything after the dealers' messages have arrived; with `split`, the output slices go where it says instead of `out`
+    void finish(const std::vector<Slice>& split = {}) {
         const size_t n = n_, t = t_, K = K_;
         mix(S, x_, y_);
         clear_bad(bad);
@@ -256,11 +265,18 @@ class RanSha : public Producer {
             pl_check(hbmpc_dev_check_degree(ctx_, poly_, status_, K, t + 1, t, bad, stream_), ctx_, "degree test");
         }
         // rows 2t .. n - 1 of every batch element, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
-        pl_check(hbmpc_dev_transpose(ctx_, y_ + 2 * t * n * K, n - 2 * t, K, n * K, out, n - 2 * t, n, K, nout, stream_), ctx_, "output shares");
+        const std::vector<Slice> whole = {{out, nout, 0, K}};
+        for (const Slice& sl : split.empty() ? whole : split)
+            pl_check(hbmpc_dev_transpose(ctx_, y_ + 2 * t * n * K + sl.k0, n - 2 * t, sl.count, n * K, sl.dst, n - 2 * t, n, K, sl.stride, stream_), ctx_,
+                     "output shares");
     }
     void run() override {
         deal();
         finish();
+    }
+    void run(const std::vector<Slice>& split) {
+        deal();
+        finish(split);
     }
     const size_t nout;  // output shares per party
     U256 *coeffs, *S, *out;  // [dealer][K][t + 1]; [dealer][recipient][K]; [party][K][n - 2t]
@@ -294,7 +310,7 @@ class RanDouSha : public Producer {
         Producer::deal(coeffs_t, t_, S_t);
         Producer::deal(coeffs_2t, 2 * t_, S_2t);
     }
-    void finish() {
+    void finish(const std::vector<Slice>& split_t = {}, const std::vector<Slice>& split_2t = {}) {
         const size_t n = n_, t = t_, K = K_;
         mix(S_t, x_, y_t_);    // RanDouShaNode::init_batch step 1
         mix(S_2t, x_, y_2t_);  // step 2
@@ -305,12 +321,19 @@ class RanDouSha : public Producer {
             pl_check(hbmpc_dev_check_double_share(ctx_, poly_t_, poly_2t_, K, n, t, bad, stream_), ctx_, "degree / equal-secret tests");
         }
         // steps 4-5: rows 0 .. t, per party in the order [k][i]  (ran_dou_sha/mod.rs:314-331)
-        pl_check(hbmpc_dev_transpose(ctx_, y_t_, t + 1, K, n * K, out_t, t + 1, n, K, nout, stream_), ctx_, "output [r]_t");
-        pl_check(hbmpc_dev_transpose(ctx_, y_2t_, t + 1, K, n * K, out_2t, t + 1, n, K, nout, stream_), ctx_, "output [r]_2t");
+        const std::vector<Slice> whole_t = {{out_t, nout, 0, K}}, whole_2t = {{out_2t, nout, 0, K}};
+        for (const Slice& sl : split_t.empty() ? whole_t : split_t)
+            pl_check(hbmpc_dev_transpose(ctx_, y_t_ + sl.k0, t + 1, sl.count, n * K, sl.dst, t + 1, n, K, sl.stride, stream_), ctx_, "output [r]_t");
+        for (const Slice& sl : split_2t.empty() ? whole_2t : split_2t)
+            pl_check(hbmpc_dev_transpose(ctx_, y_2t_ + sl.k0, t + 1, sl.count, n * K, sl.dst, t + 1, n, K, sl.stride, stream_), ctx_, "output [r]_2t");
     }
     void run() override {
         deal();
         finish();
+    }
+    void run(const std::vector<Slice>& split_t, const std::vector<Slice>& split_2t) {
+        deal();
+        finish(split_t, split_2t);
     }
     const size_t nout;
     U256 *coeffs_t, *coeffs_2t, *S_t, *S_2t, *out_t, *out_2t;
@@ -330,8 +353,18 @@ class Preprocessing {
   public:
     Preprocessing(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, void* stream)
         : rs(ctx, n, t, (2 * N + (n - 2 * t) - 1) / (n - 2 * t), stream), rd(ctx, n, t, (N + t) / (t + 1), stream), tg(ctx, n, t, N, stream),
-          ctx_(ctx), stream_(stream), n_(n), N_(N) {}
+          ctx_(ctx), stream_(stream), n_(n), t_(t), N_(N) {}
     void run() {
+        const size_t t = t_;
+        if (N_ % (n_ - 2 * t) == 0 && N_ % (t + 1) == 0) {
+            // whole batch elements on both sides of every cut: the producers' output slices go straight into TripleGen's
+            // [party][N] arrays and nothing is copied
+            const size_t k1 = N_ / (n_ - 2 * t), k2 = N_ / (t + 1);
+            rs.run({{tg.a, N_, 0, k1}, {tg.b, N_, k1, k1}});
+            rd.run({{tg.rt, N_, 0, k2}}, {{tg.r2t, N_, 0, k2}});
+            tg.run();
+            return;
+        }
         rs.run();
         rd.run();
         for (size_t p = 0; p < n_; ++p) {  // the parties' lists, in the reference's order, become TripleGen's [party][N] inputs
@@ -350,7 +383,7 @@ class Preprocessing {
     void copy(U256* dst, const U256* src) { pl_check(hbmpc_memcpy_d2d(ctx_, dst, src, N_ * sizeof(U256), stream_), ctx_, "d2d"); }
     hbmpc_ctx* ctx_;
     void* stream_;
-    size_t n_, N_;
+    size_t n_, t_, N_;
 };
 
 }  // namespace hbmpc

@@ -272,12 +272,13 @@ class RanSha(_Producer):
     def deal(self):
         self._deal(self.coeffs, self.t, self.S)
 
-    def run(self, check=True):
+    def run(self, check=True, out_split=None):
         self.deal()
-        self.finish(check)
+        self.finish(check, out_split)
 
-    def finish(self, check=True):
-        """everything after the dealers' messages have arrived (tests corrupt S in between)"""
+    def finish(self, check=True, out_split=None):
+        """everything after the dealers' messages have arrived (tests corrupt S in between).  out_split: instead of self.out,
+        write batch elements [k0, k0 + count) of every party's list to dst + party * stride: (dst, stride, k0, count), ..."""
         e, n, t, K, s, U = self.eng, self.n, self.t, self.K, self.stream, self.U
         self._mix(self.S, self.x, self.y)
         # verifier i < 2t: recover_secret of the K columns from the first verify_senders parties' shares, then the exact-degree
@@ -289,8 +290,9 @@ class RanSha(_Producer):
                                                summary_d=self.summ, stream=s), e, "verifier reconstruction")
             _check(e.dev_check_degree(self.poly, self.status, K, t + 1, t, self.bad, s), e, "degree test")
         # output: rows 2t .. n - 1 of every batch element, per party in the order [k][i - 2t]
-        _check(e.dev_transpose(self.y + 2 * t * n * K * U, n - 2 * t, K, n * K, self.out, n - 2 * t, batch=n, src_batch_stride=K,
-                               dst_batch_stride=self.nout, stream=s), e, "output shares")
+        for dst, stride, k0, cnt in (out_split or [(self.out, self.nout, 0, K)]):
+            _check(e.dev_transpose(self.y + (2 * t * n * K + k0) * U, n - 2 * t, cnt, n * K, dst, n - 2 * t, batch=n, src_batch_stride=K,
+                                   dst_batch_stride=stride, stream=s), e, "output shares")
         if check:
             bad, first = self._bad()
             if bad:
@@ -340,11 +342,12 @@ class RanDouSha(_Producer):
         self._deal(self.coeffs_t, self.t, self.S_t)           # DouShaNode::init_batch: both sharings of every secret
         self._deal(self.coeffs_2t, 2 * self.t, self.S_2t)
 
-    def run(self, check=True):
+    def run(self, check=True, out_split_t=None, out_split_2t=None):
         self.deal()
-        self.finish(check)
+        self.finish(check, out_split_t, out_split_2t)
 
-    def finish(self, check=True):
+    def finish(self, check=True, out_split_t=None, out_split_2t=None):
+        """out_split_*: as RanSha.finish -- where the two output lists go instead of self.out_t / self.out_2t"""
         e, n, t, K, s, U = self.eng, self.n, self.t, self.K, self.stream, self.U
         self._mix(self.S_t, self.x, self.y_t)                 # RanDouShaNode::init_batch step 1
         self._mix(self.S_2t, self.x, self.y_2t)               # step 2
@@ -354,9 +357,11 @@ class RanDouSha(_Producer):
             _check(e.dev_batch_interpolate(ids, self.y_t + i * n * K * U, K, K, n, self.poly_t, self.deg, s), e, "interpolate [r]_t")
             _check(e.dev_batch_interpolate(ids, self.y_2t + i * n * K * U, K, K, n, self.poly_2t, self.deg, s), e, "interpolate [r]_2t")
             _check(e.dev_check_double_share(self.poly_t, self.poly_2t, K, n, t, self.bad, s), e, "degree / equal-secret tests")
-        for y, out in ((self.y_t, self.out_t), (self.y_2t, self.out_2t)):      # steps 4-5: rows 0 .. t
-            _check(e.dev_transpose(y, t + 1, K, n * K, out, t + 1, batch=n, src_batch_stride=K, dst_batch_stride=self.nout, stream=s), e,
-                   "output double shares")
+        for y, split in ((self.y_t, out_split_t or [(self.out_t, self.nout, 0, K)]),
+                         (self.y_2t, out_split_2t or [(self.out_2t, self.nout, 0, K)])):      # steps 4-5: rows 0 .. t
+            for dst, stride, k0, cnt in split:
+                _check(e.dev_transpose(y + k0 * U, t + 1, cnt, n * K, dst, t + 1, batch=n, src_batch_stride=K, dst_batch_stride=stride,
+                                       stream=s), e, "output double shares")
         if check:
             bad, first = self._bad()
             if bad:
@@ -389,8 +394,16 @@ class Preprocessing:
         self.tg = TripleGen(eng, n, t, N, stream)
 
     def run(self, check=True):
-        e, n, N, s = self.eng, self.n, self.N, self.stream
+        e, n, t, N, s = self.eng, self.n, self.t, self.N, self.stream
         U = self.rs.U
+        if N % (n - 2 * t) == 0 and N % (t + 1) == 0:
+            # whole batch elements on both sides of every cut: the producers' output slices go straight into TripleGen's
+            # [party][N] arrays (a = the first N of a party's list, b = the next N) and nothing is copied
+            k1, k2 = N // (n - 2 * t), N // (t + 1)
+            self.rs.run(check, out_split=[(self.tg.a, N, 0, k1), (self.tg.b, N, k1, k1)])
+            self.rd.run(check, out_split_t=[(self.tg.rt, N, 0, k2)], out_split_2t=[(self.tg.r2t, N, 0, k2)])
+            self.tg.run(check)
+            return
         self.rs.run(check)
         self.rd.run(check)
         for p in range(n):   # the parties' lists, in the reference's order, become TripleGen's [party][N] inputs

@@ -121,8 +121,8 @@ static void fpmul(void* stream) {
 
 // dealers' polynomials -> RanSha / DouSha + RanDouSha -> TripleGen, all on the device; the opened c must equal a * b
 // for the secrets the producers' outputs open to, and tampering with one dealt share must turn the verdict
-static void preprocessing(void* stream) {
-    const size_t n = 7, t = 2, groups = 4, N = groups * (2 * t + 1);
+static void preprocessing(void* stream, size_t groups) {  // groups = 3: N = 15 divides into whole batch elements (the slices go straight into TripleGen's arrays)
+    const size_t n = 7, t = 2, N = groups * (2 * t + 1);
     Preprocessing pre(context(), n, t, N, stream);
     const size_t Krs = pre.rs.nout / (n - 2 * t), Krd = pre.rd.nout / (t + 1);
     std::vector<U256> co(n * Krs * (t + 1)), ct(n * Krd * (t + 1)), c2t(n * Krd * (2 * t + 1));
@@ -163,7 +163,8 @@ int main() {
     std::printf("fpmul\n");
     fpmul(stream);
     std::printf("preprocessing (RanSha, RanDouSha, TripleGen)\n");
-    preprocessing(stream);
+    preprocessing(stream, 4);
+    preprocessing(stream, 3);
     pl_check(hbmpc_stream_destroy(context(), stream), context(), "stream_destroy");
     std::printf(g_failed ? "%d CHECKS FAILED\n" : "pipelines passed (%d failures)\n", g_failed);
     return g_failed ? 1 : 0;

@@ -100,8 +100,8 @@ def test_randousha_matches_the_oracle(field, n, t, K):
         eng.close()
 
 
-@pytest.mark.parametrize("n,t,groups", [(4, 1, 3), (7, 2, 4), (16, 5, 2)])
-def test_preprocessing_chain_from_dealers_to_triples(n, t, groups):
+@pytest.mark.parametrize("n,t,groups", [(4, 1, 3), (7, 2, 4), (16, 5, 2), (4, 1, 2), (7, 2, 3), (16, 5, 6)])   # the last three: N divides into
+def test_preprocessing_chain_from_dealers_to_triples(n, t, groups):                                                 # whole batch elements (no copies)
     """dealers' polynomials -> RanSha -> a, b; DouSha + RanDouSha -> ([r]_t, [r]_2t); TripleGen -> [c]_t, nothing leaves the
     device in between.  Checked against the oracle end to end: every party's c share equals the restatement's, and the
     shares reconstruct to a * b."""
