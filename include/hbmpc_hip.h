@@ -331,8 +331,11 @@ ShareErrorCode hbmpc_truncpr_finalize(hbmpc_ctx* ctx, const U256* a, const U256*
 /* TripleGenNode::init_batch for `parties` simulated parties in one launch: [ab - r]_2t = a_i b_i - r2t_i per element
  * (triple_gen/triple_generation.rs:333-340) followed by the BatchRecon encode of the chunks of d + 1 = 2t + 1 values
  * (batch_recon/batch_recon.rs:157-165): a, b, r2t are [parties][G (d+1)], y_out is [parties][n][G] exactly as
- * hbmpc_dev_vandermonde_apply_parties writes it.  Where a fused kernel exists (either field, domains up to 16 points,
- * d + 1 in {3, 5, 7, 9, 11}) the local products never touch HBM; other shapes -- and, over Fr when tmp_dev is given,
+ * hbmpc_dev_vandermonde_apply_parties writes it.  Where a fused kernel exists the local products never touch HBM: over Fr,
+ * batches of at least 2^17 chunks over all parties on domains of 16 or 32 points whose pair table fits one CU's LDS
+ * (n / 2 rounded up to a power of two, times (d + 1) KB + 256 bytes, <= 160 KB; 2 <= d + 1 <= 15) compute the products
+ * inside the matrix-core encode (csrc/kernels_mfma_bfly.hpp, TRIPLE); either field, domains up to 16 points,
+ * d + 1 in {3, 5, 7, 9, 11}: the fused FFT kernel; other shapes -- and, over Fr when tmp_dev is given,
  * batches of at most 2 048 chunks over all parties, where two short launches beat the one long one (the small field's
  * fused kernel is light at every size and always runs when it covers the shape) -- run the two launches through
  * tmp_dev (parties G (d+1) elements; may be NULL only when the fused kernel applies -- InvalidInput otherwise).  Results are
