@@ -1217,6 +1217,7 @@ static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const voi
         const int nwg = ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus;
         if (half * mf_bfly_row_bytes(dp1) <= 160 * 1024 && mf::mf_plan_pairs((int)half, (int)half, nwg, &ma)) {
             const uint32_t* tab;
+            std::array<size_t, 5> aux = {0, 0, 0, 0, 0};  // aux[0]: the table's words (0: the digit-sum bound could not be proved)
             // rows alpha_j^i R, R = 2^261: the kernel hands over (a b - r2t) / R (one Montgomery reduction, no conversions)
             ShareErrorCode rc = get_table(ctx, key("mfbflyR", {n, dp1}, ctx->impl), [&] {
                 std::vector<HFr> el = domain_elements<HFr>(n, n);
@@ -1228,16 +1229,18 @@ static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const voi
                     HFr p = R;
                     for (size_t k = 0; k < dp1; ++k) V[j][k] = p, p = p * el[j];
                 }
-                return build_mfma_bfly_table(V, dp1, half);
-            }, &tab);
+                std::vector<uint32_t> tbl = build_mfma_bfly_table(V, dp1, half);
+                aux[0] = tbl.size();
+                return tbl;
+            }, &tab, &aux);
             if (rc != ShareSuccess) return rc;
             ma.in = (const uint8_t*)a, ma.in_b = (const uint8_t*)b, ma.in_r = (const uint8_t*)r2t;
             ma.parties = (int)parties, ma.G = G, ma.in_chunk_major = 1, ma.nv = 0;
             ma.table = (const uint8_t*)tab, ma.half = (int)half, ma.nout = (int)n;
             ma.out = (uint8_t*)y, ma.out_party_major = 1, ma.out_stride = G;
             const int mi = (int)dp1;
-            if (launch_mfma_bfly_a(mi, ma, ctx->device, s) || launch_mfma_bfly_b(mi, ma, ctx->device, s) ||
-                launch_mfma_bfly_c(mi, ma, ctx->device, s) || launch_mfma_bfly_d(mi, ma, ctx->device, s)) {
+            if (aux[0] != 0 && (launch_mfma_bfly_a(mi, ma, ctx->device, s) || launch_mfma_bfly_b(mi, ma, ctx->device, s) ||
+                                launch_mfma_bfly_c(mi, ma, ctx->device, s) || launch_mfma_bfly_d(mi, ma, ctx->device, s))) {
                 HIP_TRY(ctx, hipGetLastError());
                 return ShareSuccess;
             }
