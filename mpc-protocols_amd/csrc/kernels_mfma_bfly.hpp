@@ -15,6 +15,10 @@
 // [lane half][16] as int32: bE for the even accumulator and bT for the odd one, with bE + bT = the plain bias of row p and
 // bE - bT = a bias of row p + half (digit representation adjusted to the parity of the first, see
 // tables_mfma.hpp::build_mfma_bfly_table).  A point without a partner (p + half >= nout) has bT = 0 and no second output.
+//
+// Any n x m map whose rows p and p + half differ by the sign of the odd columns fits: the Vandermonde encode, the same with
+// its inputs given as rows (the producers' n x n mixing step), and the inverse transform (Lagrange interpolation through
+// all points of a full domain, hbmpc_dev_batch_interpolate).
 #pragma once
 #include "kernels_mfma.hpp"
 
@@ -26,12 +30,12 @@ constexpr int MF_BFLY_BIAS = 256;
 // NP > 0: every role has exactly NP pairs (the host plans it so) and the pair loop is unrolled
 // ABL: timing-only ablations for tools/ubench_mfma_bfly.hip (the library's instances have ABL = 0): 1 = no epilogue arithmetic
 // (the stores stay), 2 = no MFMAs, 4 = no LDS operand reads either, 8 = (TRIPLE) no field products
-// TRIPLE: the encode of triple generation -- the inputs are the local products c = a b - r2t of three arrays (triple_gen,
-// honeybadger/triple_gen/mod.rs:181-260: the shares of a b are masked with the degree-2t randomness before they are opened),
-// computed in this kernel: lane (chunk, h) multiplies the coefficients of its chunk whose index has parity h (one lazy product
-// and one Montgomery reduction each, fr_u29.hpp) and one v_permlane32_swap per word hands the halves round so that every lane ends up with its 16 bytes of every
-// coefficient -- the B operands, without a trip through memory or the LDS.  The tile index then runs over parties x tiles
-// (x[P][G][M] -> y[P][n][G]).
+// TRIPLE: the encode of triple generation -- the inputs are the local products a b - r2t of three arrays
+// (triple_gen/triple_generation.rs:333-340: the product of the parties' shares, masked with the degree-2t randomness before
+// it is opened), computed in this kernel: lane (chunk, h) multiplies the coefficients of its chunk whose index has parity h
+// (one lazy product and one Montgomery reduction each, fr_u29.hpp) and one v_permlane32_swap per word hands the halves
+// round so that every lane ends up with its 16 bytes of every coefficient -- the B operands, without a trip through memory
+// or the LDS.  The tile index then runs over parties x tiles (x[P][G][M] -> y[P][n][G]).
 // DEG: the outputs of a chunk are the coefficients of a polynomial (out chunk-major, one role) and a.ncoeffs[g] receives its
 // degree -- the index of the highest nonzero coefficient, 0 for the zero polynomial (DensePolynomial::degree(), what the
 // RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it.
