@@ -39,7 +39,13 @@ constexpr int MF_BFLY_BIAS = 256;
 // DEG: the outputs of a chunk are the coefficients of a polynomial (out chunk-major, one role) and a.ncoeffs[g] receives its
 // degree -- the index of the highest nonzero coefficient, 0 for the zero polynomial (DensePolynomial::degree(), what the
 // RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it.
-template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false>
+// LINES (chunk-major inputs): a tile's M KB are requested as whole lines -- lane l takes 16-byte piece i * 64 + l -- and
+// turned into the operand layout through a wave-private LDS slot (chunk c at c * (32 M + 16) bytes: the 16 bytes of padding
+// keep the operand reads, 16 bytes per lane at that stride, free of bank conflicts for M = 6), instead of M 16-byte gathers
+// per lane at a stride of 32 M bytes.  The LDS then holds the table and WAVES slots.
+template <int M>
+constexpr int bfly_slot_bytes() { return 32 * (M * 32 + 16); }
+template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false, bool LINES = false>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     static_assert(M >= 2 && M <= 16, "digit sums must stay below 0xff0000 (tables_mfma.hpp: proved per table for M = 16)");
     constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
@@ -72,9 +78,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     constexpr bool STATIC = NP > 0;
     // inputs: chunk-major x[G][M] (compute_shares, apply_vandermonde) or M rows, row i at in + rows[i] * row_stride * 32 (the
     // producers' mixing step reads the dealt shares where the dealers' encodes left them: S[dealer][..])
+    [[maybe_unused]] uint32_t waddr[LINES ? M : 1];  // where this lane's piece i of a tile goes in the slot
+    [[maybe_unused]] uint8_t* slot = lds + (size_t)role.nrows * ROWB + (size_t)wave * bfly_slot_bytes<M>();
+    if constexpr (LINES) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const uint32_t byte = (uint32_t)(i * 64 + lane) * 16u;
+            waddr[i] = byte / (M * 32u) * (M * 32u + 16u) + byte % (M * 32u);
+        }
+    }
     auto load_inputs = [&](size_t t, v4i (&dst)[M]) {
         const size_t gi = t * 32 + c;
         const uint32_t g = (uint32_t)(gi < a.G ? gi : a.G - 1);
+        if constexpr (LINES) {
+            const size_t total = a.G * (size_t)(M * 32), tb = t * 32 * (size_t)(M * 32);
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const size_t off = tb + (size_t)(i * 64 + lane) * 16;
+                dst[i] = *reinterpret_cast<const v4i*>(a.in + (off + 16 <= total ? off : total - 16));  // past the end: any in-bounds piece
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             if (a.in_chunk_major) {
@@ -178,6 +202,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         }
     };
     auto process_tile = [&](size_t t, v4i (&data)[M]) {
+        if constexpr (LINES) {  // pieces -> slot -> operands (the same wave writes and reads: no barrier)
+#pragma unroll
+            for (int i = 0; i < M; ++i) *reinterpret_cast<v4i*>(slot + waddr[i]) = data[i];
+#pragma unroll
+            for (int i = 0; i < M; ++i) data[i] = *reinterpret_cast<const v4i*>(slot + c * (M * 32 + 16) + i * 32 + 16 * h);
+        }
 #pragma unroll
         for (int i = 0; i < M; ++i) data[i] = flip(data[i]);
         pairs_of_tile(t, data, a.out);

@@ -46,6 +46,7 @@ static float time_ms(F f, int reps) {
     return ms / reps;
 }
 static int g_nwg = 256;
+static int bad_lines = 0;
 
 template <int M, int WAVES, int NR, int ABL = 0>
 static void launch_plain(mf::MfmaRowsArgs a, int rows) {
@@ -160,6 +161,18 @@ static int run_triple(int n, size_t G, int P, int reps) {
     return errors;
 }
 
+template <int M, int WAVES, int NP>
+static void launch_lines(mf::MfmaRowsArgs a, int pairs) {
+    constexpr int ROWB = M * 1024 + 256;
+    if (!mf::mf_plan_pairs(pairs, (160 * 1024) / ROWB, g_nwg, &a)) exit(3);
+    if (mf::mf_max_role_rows(a) != NP || a.nroles != 1) exit(4);
+    const size_t shm = (size_t)NP * ROWB + (size_t)WAVES * mf::bfly_slot_bytes<M>();
+    if (shm > 160 * 1024) exit(5);
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, 0, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, 0, false, 1, false, true>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+}
+
 template <int M, int WP, int NRP, int NP>
 static int run(const char* name, int n, size_t G, int reps) {
     const size_t size = domain_size(n), half = size / 2;
@@ -248,6 +261,21 @@ static int run(const char* name, int n, size_t G, int reps) {
         printf("   ablations, 12 waves: no epilogue %.4f | no MFMA %.4f | no MFMA, no table reads %.4f | neither MFMA nor epilogue %.4f | memory traffic only %.4f\n", a1, a2, a6, a3, a7);
     }
 #endif
+    if constexpr (M <= 8) {
+        if ((size_t)NP == half) {
+            CK(hipMemset(d_y1, 0xee, (size_t)n * G * 32));
+            launch_lines<M, 12, NP>(ba, (int)half);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(y1.data(), d_y1, y1.size() * 8, hipMemcpyDeviceToHost));
+            size_t dd = 0;
+            for (size_t i = 0; i < y0.size(); ++i) dd += y0[i] != y1[i];
+            const float l8 = time_ms([&] { launch_lines<M, 8, NP>(ba, (int)half); }, reps);
+            const float l12 = time_ms([&] { launch_lines<M, 12, NP>(ba, (int)half); }, reps);
+            const float l16 = time_ms([&] { launch_lines<M, 16, NP>(ba, (int)half); }, reps);
+            printf("   inputs as whole lines through a wave-private LDS slot: %zu words differ; 8 waves %.4f ms, 12 waves %.4f, 16 waves %.4f\n", dd, l8, l12, l16);
+            bad_lines += dd != 0;
+        }
+    }
     const double bytes = (double)G * (M + n) * 32;
     printf("   algorithmic bytes %.1f MB: at 8 TB/s %.4f ms\n", bytes / 1e6, bytes / 8e12 * 1e3);
     CK(hipFree(d_tp)); CK(hipFree(d_tb)); CK(hipFree(d_x)); CK(hipFree(d_y0)); CK(hipFree(d_y1));
@@ -269,6 +297,7 @@ int main(int argc, char** argv) {
     bad += run<6, 16, 0, 8>("config 2 (n = 16, t = 5)", 16, G, reps);
     bad += run<11, 12, 11, 8>("config 3 (n = 31, t = 10)", 31, G, reps);
     bad += run<3, 16, 0, 4>("n = 7, t = 2", 7, G, reps);
+    bad += bad_lines;
     printf(bad ? "FAILED\n" : "all outputs identical\n");
     return bad != 0;
 }
