@@ -161,7 +161,7 @@ static int run_triple(int n, size_t G, int P, int reps) {
     return errors;
 }
 
-template <int M, int WAVES, int NP>
+template <int M, int WAVES, int NP, int ABL = 0>
 static void launch_lines(mf::MfmaRowsArgs a, int pairs) {
     constexpr int ROWB = M * 1024 + 256;
     if (!mf::mf_plan_pairs(pairs, (160 * 1024) / ROWB, g_nwg, &a)) exit(3);
@@ -169,8 +169,8 @@ static void launch_lines(mf::MfmaRowsArgs a, int pairs) {
     const size_t shm = (size_t)NP * ROWB + (size_t)WAVES * mf::bfly_slot_bytes<M>();
     if (shm > 160 * 1024) exit(5);
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, 0, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, 0, false, 1, false, true>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, ABL, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, ABL, false, 1, false, true>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 template <int M, int WP, int NRP, int NP>
@@ -272,6 +272,14 @@ static int run(const char* name, int n, size_t G, int reps) {
             const float l8 = time_ms([&] { launch_lines<M, 8, NP>(ba, (int)half); }, reps);
             const float l12 = time_ms([&] { launch_lines<M, 12, NP>(ba, (int)half); }, reps);
             const float l16 = time_ms([&] { launch_lines<M, 16, NP>(ba, (int)half); }, reps);
+#ifdef BFLY_ABLATE
+            {
+                const float e1 = time_ms([&] { launch_lines<M, 12, NP, 1>(ba, (int)half); }, reps);
+                const float e2 = time_ms([&] { launch_lines<M, 12, NP, 2>(ba, (int)half); }, reps);
+                const float e3 = time_ms([&] { launch_lines<M, 12, NP, 3>(ba, (int)half); }, reps);
+                printf("   whole lines, 12 waves: without epilogue arithmetic %.4f ms, without MFMAs %.4f, loads and stores (and the LDS round trip) only %.4f\n", e1, e2, e3);
+            }
+#endif
             printf("   inputs as whole lines through a wave-private LDS slot: %zu words differ; 8 waves %.4f ms, 12 waves %.4f, 16 waves %.4f\n", dd, l8, l12, l16);
             bad_lines += dd != 0;
         }
