@@ -139,3 +139,65 @@ def test_preprocessing_chain_from_dealers_to_triples(n, t, groups):             
     finally:
         pre.close()
         eng.close()
+
+
+def test_producers_at_a_size_that_takes_the_large_batch_kernels():
+    """K = 20 000 batch elements per dealer, n = 16: the dealers' encodes, the n x n mixing step over the dealt rows
+    (hbmpc_dev_vandermonde_apply_rows, d + 1 = 16) and the RanDouSha verifiers' full-domain interpolation with its degrees all run
+    on the point-pair matrix-core kernel here (the small cases above stay below its thresholds).  Every party's outputs for sampled
+    batch elements against the oracle, the verifiers' verdicts, and a tampered share caught at this size too."""
+    from oracle import cref as O
+    S = SFR
+    n, t, K = 16, 5, 20000
+    pkg = load_package()
+    eng = pkg.Engine(0)
+    rng = random.Random(99)
+    sample = sorted(rng.sample(range(K), 12) + [0, K - 1])
+    try:
+        co = O.fill_random(1234, n * K * (t + 1)).reshape(n, K, t + 1, 4)
+        rs = pkg.pipelines.RanSha(eng, n, t, K)
+        rs.upload(co)
+        rs.run(check=True)
+        got = rs.download().reshape(n, K, n - 2 * t, 4)
+        pol = [[u256_to_ints(co[p, k]) for k in sample] for p in range(n)]
+        want, ok = S.ransha(pol, n, t)
+        assert all(ok)
+        for j in range(n):
+            assert u256_to_ints(np.ascontiguousarray(got[j, sample]).reshape(-1, 4)) == want[j], j
+        # one dealt share changed: caught by the verifiers, first failing column reported
+        rs.deal()
+        k_bad = 12345
+        off = ((3 * n + 7) * K + k_bad) * 32
+        cur = eng._new((1,))
+        eng.d2h(cur, rs.S + off)
+        eng.sync()
+        eng.h2d(rs.S + off, ints_to_u256([(u256_to_ints(cur)[0] + 1) % S.R_MOD]))
+        with pytest.raises(RuntimeError, match="RanSha"):
+            rs.finish(check=True)
+        assert rs._bad()[1] == k_bad
+        rs.close()
+
+        ct = O.fill_random(77, n * K * (t + 1)).reshape(n, K, t + 1, 4)
+        c2t = O.fill_random(78, n * K * (2 * t + 1)).reshape(n, K, 2 * t + 1, 4)
+        c2t[:, :, 0] = ct[:, :, 0]
+        rd = pkg.pipelines.RanDouSha(eng, n, t, K)
+        rd.upload(ct, c2t)
+        rd.run(check=True)
+        a, b = rd.download()
+        a, b = a.reshape(n, K, t + 1, 4), b.reshape(n, K, t + 1, 4)
+        want_t, want_2t, ok = S.randousha([[u256_to_ints(ct[p, k]) for k in sample] for p in range(n)],
+                                          [[u256_to_ints(c2t[p, k]) for k in sample] for p in range(n)], n, t)
+        assert all(ok)
+        for j in range(n):
+            assert u256_to_ints(np.ascontiguousarray(a[j, sample]).reshape(-1, 4)) == want_t[j], j
+            assert u256_to_ints(np.ascontiguousarray(b[j, sample]).reshape(-1, 4)) == want_2t[j], j
+        # a dealer whose degree-2t sharing hides another secret in ONE column: every verifier's equal-secret test fails there
+        c2t[5, 4321, 0, 0] ^= np.uint64(1)
+        rd.upload(ct, c2t)
+        with pytest.raises(RuntimeError, match="RanDouSha"):
+            rd.run(check=True)
+        bad, first = rd._bad()
+        assert bad == n - (t + 1) and first == 4321
+        rd.close()
+    finally:
+        eng.close()
