@@ -14,8 +14,11 @@
 // that drop what must not be written) so that hipcc counts the vector memory operations between a request and its use.
 #pragma once
 #include <utility>
+#ifndef HBMPC_MFS_ABL  // timing-only ablations of tools/ubench_mfma_stream.hip: 1 = claimed values not loaded, 2 = no output stores, 4 = every tile re-reads tile 0
+#define HBMPC_MFS_ABL 0
+#endif
 
-#include "kernels_mfma.hpp"
+#include "../mpc-protocols_amd/csrc/kernels_mfma.hpp"
 
 namespace hbmpc {
 namespace mf {
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows_stream(MfmaRowsArgs a)
     // address registers per slab: with global loads hipcc keeps 77 hoisted 64-bit addresses and spills)
     const __amdgpu_buffer_rsrc_t stream_rsrc = rt_rsrc(a.table + (size_t)NRES * ROWB, (uint32_t)((NR - NRES) * ROWB));
     auto load_inputs = [&](size_t t, v4i (&dst)[M]) {
-        const size_t gi = t * 32 + c;
+        const size_t gi = ((HBMPC_MFS_ABL & 4) ? (t & 63) : t) * 32 + c;
         const uint32_t g = (uint32_t)(gi < a.G ? gi : a.G - 1);
 #pragma unroll
         for (int i = 0; i < M; ++i) {
@@ -79,6 +82,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows_stream(MfmaRowsArgs a)
 #pragma unroll
         for (int i = 0; i < M; ++i) data[i] = flip(data[i]);
         auto load_ys = [&](int r) {  // claimed values of verify row r
+            if constexpr ((HBMPC_MFS_ABL & 1) != 0) return data[r % M];
             uint32_t ri = (uint32_t)a.rows[M + r];
             asm volatile("" : "+s"(ri));
             return *reinterpret_cast<const v4i*>(a.in + (size_t)ri * a.row_stride * 32 + (g * 32u + 16u * h));
@@ -152,9 +156,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows_stream(MfmaRowsArgs a)
                 uint8_t* qb = a.out_party_major ? a.out + (size_t)k32 * a.out_stride * 32 : a.out + (size_t)k32 * 32;  // wave-uniform
                 v4i val;
                 val[0] = (int)Rw[0], val[1] = (int)Rw[1], val[2] = (int)Rw[2], val[3] = (int)Rw[3];
-                __builtin_amdgcn_raw_buffer_store_b128(val, rt_rsrc(qb, out_bytes), (int)qo, 0, 0);
+                if (!(HBMPC_MFS_ABL & 2) || val[0] == 0x12345) __builtin_amdgcn_raw_buffer_store_b128(val, rt_rsrc(qb, out_bytes), (int)qo, 0, 0);
             }
         }, std::make_integer_sequence<int, NR>{});
+        if constexpr ((HBMPC_MFS_ABL & 1) != 0) bad &= (uint32_t)a.in_chunk_major;  // timing only: zero at run time, the verify arithmetic stays
         // the verdict of the chunk (NV == 0: every chunk is accepted)
         const unsigned long long m = __ballot(bad != 0);
         const uint32_t m32 = (uint32_t)m | (uint32_t)(m >> 32);

@@ -11,7 +11,7 @@
 #include <random>
 #include <vector>
 
-#include "../mpc-protocols_amd/csrc/kernels_mfma_stream.hpp"
+#include "kernels_mfma_stream.hpp"
 #include "../mpc-protocols_amd/csrc/tables_mfma.hpp"
 
 using namespace hbmpc;
@@ -48,14 +48,14 @@ static float time_ms(F f, int reps) {
     return ms / reps;
 }
 constexpr int M = 11;
-template <int NR>
+template <int NR, int CG = 1, int W = 12>
 static void launch_two_roles(mf::MfmaRowsArgs a, int rows) {
     constexpr int ROWB = M * 1024 + 128;
     if (!mf::mf_plan_roles(rows, a.nv, (160 * 1024) / ROWB, 256, &a)) exit(3);
     const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, 1, 12, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, 1, 12, NR>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * 12), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, W, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, W, NR>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * W), shm, 0, a);
 }
 template <int W, int NV, int NO, int NRES, int D, int DL = 3, int YD = 1, bool DB = true>
 static void launch_stream(mf::MfmaRowsArgs a, int nwg = 256) {
@@ -203,6 +203,7 @@ int main(int argc, char** argv) {
     reset();
     launch_stream<12, nv, M, 14, 4>(b);
     compare("stream W=12 NRES=14 D=4 (clean)", false);
+
 #else
     fprintf(stderr, "TIMING ONLY: the streamed slabs are read from the LDS (wrong operands)\n");
     {
@@ -231,9 +232,7 @@ int main(int argc, char** argv) {
         TIME(12, 14, 4, 3, 1, true)
         TIME(12, 14, 4, 3, 1, false)
         TIME(16, 14, 4, 3, 1, false)
-        TIME(16, 14, 2, 2, 1, false)
         TIME(8, 14, 4, 3, 1, true)
-        TIME(8, 14, 4, 3, 1, false)
         fflush(stdout);
     }
     uint32_t cnt[4];
