@@ -1,45 +1,25 @@
-// kernels_mfma_bfly.hpp -- the encode (apply_vandermonde, common/share/mod.rs:50-76; compute_shares,
-// robust_interpolate.rs:52-82) on the matrix cores with HALF the MFMAs of kernels_mfma.hpp.
-//
-// The evaluation points are the powers of a root of unity of order size = 2 half (common/mod.rs:51-68), so
-// alpha_{k + half} = -alpha_k and, with the polynomial split by coefficient parity,
-//     p(alpha_k)        = E_k + T_k          E_k = sum_{i even} c_i alpha_k^i
-//     p(alpha_{k+half}) = E_k - T_k          T_k = sum_{i odd}  c_i alpha_k^i
-// E_k and T_k are constant-matrix maps of the even / odd coefficients: in the byte-digit formulation (tables_mfma.hpp)
-// their digit sums come from the SAME table slabs as row k of the plain kernel -- slab i goes to the accumulator of its
-// parity -- and the sum / difference is taken on the un-normalised digit sums (exact integers, far from overflow)
-// before the one carry pass and reduction each output needs anyway.  A pair of outputs so costs M MFMAs and M KB of
-// LDS operand traffic per 32 chunks instead of 2 M, plus 16 vector adds.
-//
-// Table row p (pair p): the M slabs of point p exactly as build_mfma_table lays them out, then two accumulator biases
-// [lane half][16] as int32: bE for the even accumulator and bT for the odd one, with bE + bT = the plain bias of row p and
-// bE - bT = a bias of row p + half (digit representation adjusted to the parity of the first, see
-// tables_mfma.hpp::build_mfma_bfly_table).  A point without a partner (p + half >= nout) has bT = 0 and no second output.
-//
-// Any n x m map whose rows p and p + half differ by the sign of the odd columns fits: the Vandermonde encode, the same with
-// its inputs given as rows (the producers' n x n mixing step), and the inverse transform (Lagrange interpolation through
-// all points of a full domain, hbmpc_dev_batch_interpolate).
+// kernels_mfma_bfly_lab.hpp -- laboratory forms of k_mfma_bfly (csrc/kernels_mfma_bfly.hpp), for the microbenchmarks under tools/ only;
+// nothing here is compiled into the library.  k_mfma_bfly_lab<M, WAVES, NP, ABL, TRIPLE, TRIPLE_DEPTH, DEG, LINES>: the production
+// kernel's text plus
+//   ABL    timing-only ablations: 1 = no epilogue arithmetic (the stores stay and depend on every accumulator register),
+//          2 = no MFMAs (EVERY dword of every loaded input is folded into the accumulators), 4 = no LDS operand reads either,
+//          8 = (TRIPLE) no field products (the three operands of every element are XOR-ed: every load stays)
+//   LINES  (chunk-major inputs) a tile's M KB requested as whole lines -- lane l takes 16-byte piece i * 64 + l -- and turned into
+//          the operand layout through a wave-private LDS slot (chunk c at c * (32 M + 16) bytes), instead of M 16-byte gathers per
+//          lane at a stride of 32 M bytes; bit-identical, not faster (profiles/r03_mfma_bfly_followup.txt)
+// Round 3's ablations folded only one dword of each loaded vector, and hipcc dropped about half of the input loads as dead
+// (VERDICT r3 / ADVICE r3).  Check every ablated instance before quoting its time:
+//   python3 tools/count_loads.py tools/ubench_mfma_bfly.hip -DBFLY_ABLATE
 #pragma once
-#include "kernels_mfma.hpp"
+#include "../mpc-protocols_amd/csrc/kernels_mfma_bfly.hpp"
 
 namespace hbmpc {
 namespace mf {
 
-constexpr int MF_BFLY_BIAS = 256;
-
-// NP > 0: every role has exactly NP pairs (the host plans it so) and the pair loop is unrolled
-// (Timing-only ablations and the whole-line read path of round 3 live in tools/kernels_mfma_bfly_lab.hpp.)
-// TRIPLE: the encode of triple generation -- the inputs are the local products a b - r2t of three arrays
-// (triple_gen/triple_generation.rs:333-340: the product of the parties' shares, masked with the degree-2t randomness before
-// it is opened), computed in this kernel: lane (chunk, h) multiplies the coefficients of its chunk whose index has parity h
-// (one lazy product and one Montgomery reduction each, fr_u29.hpp) and one v_permlane32_swap per word hands the halves
-// round so that every lane ends up with its 16 bytes of every coefficient -- the B operands, without a trip through memory
-// or the LDS.  The tile index then runs over parties x tiles (x[P][G][M] -> y[P][n][G]).
-// DEG: the outputs of a chunk are the coefficients of a polynomial (out chunk-major, one role) and a.ncoeffs[g] receives its
-// degree -- the index of the highest nonzero coefficient, 0 for the zero polynomial (DensePolynomial::degree(), what the
-// RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it.
-template <int M, int WAVES, int NP = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false>
-__global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
+template <int M>
+constexpr int bfly_slot_bytes() { return 32 * (M * 32 + 16); }
+template <int M, int WAVES, int NP = 0, int ABL = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false, bool LINES = false>
+__global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly_lab(MfmaRowsArgs a) {
     static_assert(M >= 2 && M <= 16, "digit sums must stay below 0xff0000 (tables_mfma.hpp: proved per table for M = 16)");
     constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
     constexpr int NT = 64 * WAVES;
@@ -71,9 +51,27 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     constexpr bool STATIC = NP > 0;
     // inputs: chunk-major x[G][M] (compute_shares, apply_vandermonde) or M rows, row i at in + rows[i] * row_stride * 32 (the
     // producers' mixing step reads the dealt shares where the dealers' encodes left them: S[dealer][..])
+    [[maybe_unused]] uint32_t waddr[LINES ? M : 1];  // where this lane's piece i of a tile goes in the slot
+    [[maybe_unused]] uint8_t* slot = lds + (size_t)role.nrows * ROWB + (size_t)wave * bfly_slot_bytes<M>();
+    if constexpr (LINES) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const uint32_t byte = (uint32_t)(i * 64 + lane) * 16u;
+            waddr[i] = byte / (M * 32u) * (M * 32u + 16u) + byte % (M * 32u);
+        }
+    }
     auto load_inputs = [&](size_t t, v4i (&dst)[M]) {
         const size_t gi = t * 32 + c;
         const uint32_t g = (uint32_t)(gi < a.G ? gi : a.G - 1);
+        if constexpr (LINES) {
+            const size_t total = a.G * (size_t)(M * 32), tb = t * 32 * (size_t)(M * 32);
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const size_t off = tb + (size_t)(i * 64 + lane) * 16;
+                dst[i] = *reinterpret_cast<const v4i*>(a.in + (off + 16 <= total ? off : total - 16));  // past the end: any in-bounds piece
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < M; ++i) {
             if (a.in_chunk_major) {
@@ -134,8 +132,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < M; ++i) {
-                    if (i + D - 1 < M) av[(i + D - 1) % D] = *reinterpret_cast<const v4i*>(tab_lane + (i + D - 1) * 1024);
-                    if (i & 1) accT = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i % D], data[i], accT, 0, 0, 0);
+                    if (i + D - 1 < M && !(ABL & 4)) av[(i + D - 1) % D] = *reinterpret_cast<const v4i*>(tab_lane + (i + D - 1) * 1024);
+                    if (ABL & 2) {  // no MFMA: every loaded dword of input i (and of the slab, unless ABL & 4) is folded into the accumulators
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int mix = (ABL & 4) ? data[i][k] : (av[i % D][k] ^ data[i][k]);
+                            if (i & 1) accT[(4 * i + k) & 15] ^= mix;
+                            else accE[(4 * i + k) & 15] ^= mix;
+                        }
+                    } else if (i & 1) accT = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i % D], data[i], accT, 0, 0, 0);
                     else accE = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i % D], data[i], accE, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -150,7 +155,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 uint32_t Rw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] + pt[2 * j + 1]) * H.k16 + (pe[2 * j] + pt[2 * j]);
-                reduce_words(T, Rw, H);
+                if (ABL & 1) Rw[0] = pe[0] + pt[1] + pe[1] + pt[0], Rw[1] = pe[2] + pt[3] + pe[3] + pt[2], Rw[2] = pe[4] + pt[5] + pe[5] + pt[4], Rw[3] = pe[6] + pt[7] + pe[7] + pt[6];
+                else reduce_words(T, Rw, H);
                 store_row(out, k32, true, live, qo, Rw);
                 if constexpr (DEG) note_degree(k32, true, Rw);
             }
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
                 uint32_t Rw[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] - pt[2 * j + 1]) * H.k16 + (pe[2 * j] - pt[2 * j]);
-                reduce_words(T, Rw, H);
+                if (ABL & 1) Rw[0] = pe[0] - pt[1] + pe[1] - pt[0], Rw[1] = pe[2] - pt[3] + pe[3] - pt[2], Rw[2] = pe[4] - pt[5] + pe[5] - pt[4], Rw[3] = pe[6] - pt[7] + pe[7] - pt[6];
+                else reduce_words(T, Rw, H);
                 store_row(out, k32 + (uint32_t)a.half, partner, live, qo, Rw);
                 if constexpr (DEG) note_degree(k32 + (uint32_t)a.half, partner, Rw);
             }
@@ -172,6 +179,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         }
     };
     auto process_tile = [&](size_t t, v4i (&data)[M]) {
+        if constexpr (LINES) {  // pieces -> slot -> operands (the same wave writes and reads: no barrier)
+#pragma unroll
+            for (int i = 0; i < M; ++i) *reinterpret_cast<v4i*>(slot + waddr[i]) = data[i];
+#pragma unroll
+            for (int i = 0; i < M; ++i) data[i] = *reinterpret_cast<const v4i*>(slot + c * (M * 32 + 16) + i * 32 + 16 * h);
+        }
 #pragma unroll
         for (int i = 0; i < M; ++i) data[i] = flip(data[i]);
         pairs_of_tile(t, data, a.out);
@@ -213,6 +226,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         // the 72 multiply-adds of the Montgomery reduction.  The factor R^-1 is undone by the TABLE, whose rows are
         // alpha^i R for this kernel (hbmpc_capi.hip: "mfbflyR"), so no operand is ever converted to Montgomery form.
         auto product = [&](const Slot& sl, v4i& lo, v4i& hi) {
+            if constexpr ((ABL & 8) != 0) {  // timing only: no field arithmetic, every load stays
+#pragma unroll
+                for (int k = 0; k < 4; ++k) lo[k] = sl.a[0][k] ^ sl.b[0][k] ^ sl.r[0][k], hi[k] = sl.a[1][k] ^ sl.b[1][k] ^ sl.r[1][k];
+                return;
+            }
             const F::E ea = elem(sl.a), eb = elem(sl.b), er = elem(sl.r);
             F::Acc A;
             F::acc_zero(A);

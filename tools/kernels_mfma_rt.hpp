@@ -33,7 +33,7 @@
 // stores are buffer stores, whose out-of-range form replaces the `if (live)` branches.  sched_barrier pins the order
 // "B operand request, MFMA, piece of vector work" gap by gap.
 #pragma once
-#include "../mpc-protocols_amd/csrc/kernels_mfma.hpp"
+#include "kernels_mfma_lab.hpp"  // the staged epilogue (RtEpi, rt_epi_stage)
 
 namespace hbmpc {
 namespace mf {

@@ -8,7 +8,7 @@
 #include <random>
 #include <vector>
 
-#include "../mpc-protocols_amd/csrc/kernels_mfma.hpp"
+#include "kernels_mfma_lab.hpp"
 #include "../mpc-protocols_amd/csrc/tables_mfma.hpp"
 
 using namespace hbmpc;
@@ -48,8 +48,8 @@ static void launch(mf::MfmaRowsArgs a, int rows) {
     if (!mf::mf_plan_roles(rows, a.nv, (160 * 1024) / ROWB, 256, &a)) exit(3);
     const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, 1, W, 11, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, 1, W, 11, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * W), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows_lab<M, 1, W, 11, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_rows_lab<M, 1, W, 11, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * W), shm, 0, a);
 }
 int main(int argc, char** argv) {
     const int lg = argc > 1 ? atoi(argv[1]) : 20, reps = argc > 2 ? atoi(argv[2]) : 20;

@@ -10,7 +10,7 @@
 #include <random>
 #include <vector>
 
-#include "../mpc-protocols_amd/csrc/kernels_mfma.hpp"
+#include "kernels_mfma_lab.hpp"
 #include "../mpc-protocols_amd/csrc/tables_mfma.hpp"
 
 using namespace hbmpc;
@@ -73,14 +73,14 @@ static void launch_rows(mf::MfmaRowsArgs a, int rows) {
     }
     static bool attr_set = false;
     if (!attr_set) {
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, CG, WAVES, NR, ABL, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows_lab<M, CG, WAVES, NR, ABL, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     if (NR > 0 && mf::mf_max_role_rows(a) > NR) {
         fprintf(stderr, "role rows %d exceed the static row count %d\n", mf::mf_max_role_rows(a), NR);
         exit(2);
     }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, CG, WAVES, NR, ABL, PIPE>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    hipLaunchKernelGGL((mf::k_mfma_rows_lab<M, CG, WAVES, NR, ABL, PIPE>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 // encode x[G][M] with [I ; Cv] -> evals[M + nv][G]; decode with verify rows Cv and output rows Co; check vs host

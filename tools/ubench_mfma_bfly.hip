@@ -9,7 +9,8 @@
 #include <random>
 #include <vector>
 
-#include "../mpc-protocols_amd/csrc/kernels_mfma_bfly.hpp"
+#include "kernels_mfma_bfly_lab.hpp"
+#include "kernels_mfma_lab.hpp"
 #include "../mpc-protocols_amd/csrc/tables.hpp"
 #include "../mpc-protocols_amd/csrc/tables_mfma.hpp"
 
@@ -54,8 +55,8 @@ static void launch_plain(mf::MfmaRowsArgs a, int rows) {
     if (!mf::mf_plan_roles(rows, 0, (160 * 1024) / ROWB, 256, &a)) exit(3);
     const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows<M, 1, WAVES, NR, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_rows<M, 1, WAVES, NR, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_rows_lab<M, 1, WAVES, NR, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_rows_lab<M, 1, WAVES, NR, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 template <int M, int WAVES, int NP, int ABL = 0>
 static void launch_bfly(mf::MfmaRowsArgs a, int pairs, int wgs_per_cu) {
@@ -65,8 +66,8 @@ static void launch_bfly(mf::MfmaRowsArgs a, int pairs, int wgs_per_cu) {
     const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
     if (NP > 0 && mf::mf_max_role_rows(a) > NP) exit(4);
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly_lab<M, WAVES, NP, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_bfly_lab<M, WAVES, NP, ABL>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 // the fused local product + encode of triple generation: y[P][n][G] from a, b, r2t [P][G][M]
@@ -77,8 +78,8 @@ static void launch_triple(mf::MfmaRowsArgs a, int pairs) {
     const size_t shm = (size_t)mf::mf_max_role_rows(a) * ROWB;
     if (mf::mf_max_role_rows(a) != NP || a.nroles != 1) exit(4);
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, ABL, true, SD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, ABL, true, SD>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly_lab<M, WAVES, NP, ABL, true, SD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_bfly_lab<M, WAVES, NP, ABL, true, SD>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 template <int M, int NP>
 static int run_triple(int n, size_t G, int P, int reps) {
@@ -169,8 +170,8 @@ static void launch_lines(mf::MfmaRowsArgs a, int pairs) {
     const size_t shm = (size_t)NP * ROWB + (size_t)WAVES * mf::bfly_slot_bytes<M>();
     if (shm > 160 * 1024) exit(5);
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly<M, WAVES, NP, ABL, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL((mf::k_mfma_bfly<M, WAVES, NP, ABL, false, 1, false, true>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
+    if (!attr) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&mf::k_mfma_bfly_lab<M, WAVES, NP, ABL, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL((mf::k_mfma_bfly_lab<M, WAVES, NP, ABL, false, 1, false, true>), dim3((unsigned)mf::mf_grid(a)), dim3(64 * WAVES), shm, 0, a);
 }
 
 template <int M, int WP, int NRP, int NP>
