@@ -106,6 +106,7 @@ ShareErrorCode hbmpc_create(int device, FieldKind field_kind, hbmpc_ctx** ctx_ou
 void hbmpc_destroy(hbmpc_ctx* ctx);
 const char* hbmpc_last_error(const hbmpc_ctx* ctx);
 const char* hbmpc_version(void);
+FieldKind hbmpc_field_of(const hbmpc_ctx* ctx); /* the field the context was created with */
 
 /* ---- device memory / stream helpers (for hosts without their own HIP binding) ------------ */
 /* Device buffers passed to hbmpc_dev_* should come from hbmpc_dev_alloc / hipMalloc (what torch's caching
@@ -155,6 +156,52 @@ ShareErrorCode hbmpc_graph_begin_capture(hbmpc_ctx* ctx, void* stream);
 ShareErrorCode hbmpc_graph_end_capture(hbmpc_ctx* ctx, void* stream, hbmpc_graph** graph_out);
 ShareErrorCode hbmpc_graph_launch(hbmpc_ctx* ctx, hbmpc_graph* graph, void* stream);
 void hbmpc_graph_destroy(hbmpc_graph* graph);
+
+/* ---- device-resident pipelines (all n simulated parties on one GPU) -------------------------------------------------
+ * The reference's arithmetic pipelines as opaque handles, so that the Rust node (or any C caller) gets the call
+ * sequencing, the arena layout and the capture rules from the library:
+ *   triplegen      TripleGenNode::init_batch + BatchRecon(2t) + finalize   triple_gen/triple_generation.rs:304-364,164-232
+ *   fpmul          FPMulNode::init = Multiply (Beaver, RBC path) + TruncPr  fpmul/fpmul.rs:61-110, fpmul/truncpr.rs:185-318 (Fr only)
+ *   ransha         RanShaNode: deal, n x n Vandermonde, verifiers, output   share_gen/share_gen.rs:232-289,401-454,516-530,199-203
+ *   randousha      DouShaNode deal + RanDouShaNode                           ran_dou_sha/mod.rs:371-449,569-602,314-331
+ *   preprocessing  run_preprocessing's triple part: ransha -> a, b; randousha -> r; triplegen   honeybadger/mod.rs:1239-1393
+ * Sizes: N triples (a multiple of 2t+1) / N element pairs / K batch elements per dealer.  open_senders, verify_senders: how
+ * many parties' shares an open / a RanSha verifier interpolates from; 0 = the reference's 2t + 1 (it acts as soon as that
+ * many have arrived: multiplication.rs:388, truncpr.rs:202, share_gen.rs:497).  Every buffer of a pipeline lives in ONE device
+ * block owned by the handle and is reached by name (hbmpc_pipe_buffer; elements of the context's field, [party][...] layouts):
+ *   triplegen      a, b, r2t, rt (inputs [n][N]); c (output [n][N]); Y, Z, opened, status, summary
+ *   fpmul          x, y, ta, tb, tc, rint ([n][N]), rbits ([n][m][N]) (inputs); out ([n][N]); z, rdash, osh, desh, dop, eop, cop
+ *   ransha         coeffs ([dealer][K][t+1], column 0 the secret); S ([dealer][recipient][K]); y; out ([party][K][n-2t]); bad
+ *   randousha      coeffs_t, coeffs_2t; S_t, S_2t; y_t, y_2t; out_t, out_2t ([party][K][t+1]); bad
+ *   preprocessing  its parts by name (hbmpc_pipe_part: "ransha", "randousha", "triplegen"; borrowed handles)
+ * run() only ENQUEUES on the handle's stream (checked mode, hbmpc_pipe_set_checked: it reads the summary back after every
+ * decode and returns the failing chunk's error where the reference's `?` would).  deal() / finish() are the two halves of a
+ * producer's run (tests corrupt the dealt shares in between).  capture() = two eager runs + a recorded one; replay() launches
+ * the recording (stream must be a real stream).  summary(): the last decode's hbmpc_recover_summary; verdict(): a producer's
+ * {verifier checks that failed, first failing batch element} (preprocessing: both producers) -- both synchronise.
+ * Errors: InvalidInput for shapes the reference rejects or unknown names, TypeMismatch for fpmul on a Goldilocks context. */
+typedef struct hbmpc_pipe hbmpc_pipe;
+ShareErrorCode hbmpc_pipe_triplegen_create(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, void* stream, hbmpc_pipe** pipe_out);
+ShareErrorCode hbmpc_pipe_fpmul_create(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, size_t k, size_t m, size_t open_senders,
+                                       void* stream, hbmpc_pipe** pipe_out);
+ShareErrorCode hbmpc_pipe_ransha_create(hbmpc_ctx* ctx, size_t n, size_t t, size_t K, size_t verify_senders, void* stream,
+                                        hbmpc_pipe** pipe_out);
+ShareErrorCode hbmpc_pipe_randousha_create(hbmpc_ctx* ctx, size_t n, size_t t, size_t K, void* stream, hbmpc_pipe** pipe_out);
+ShareErrorCode hbmpc_pipe_preprocessing_create(hbmpc_ctx* ctx, size_t n, size_t t, size_t N, void* stream, hbmpc_pipe** pipe_out);
+void hbmpc_pipe_destroy(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_part(hbmpc_pipe* pipe, const char* name, hbmpc_pipe** part_out);
+ShareErrorCode hbmpc_pipe_buffer(hbmpc_pipe* pipe, const char* name, void** dev_out, size_t* elements_out);
+ShareErrorCode hbmpc_pipe_upload(hbmpc_pipe* pipe, const char* name, const void* host, size_t elements);
+ShareErrorCode hbmpc_pipe_download(hbmpc_pipe* pipe, const char* name, void* host, size_t elements);
+ShareErrorCode hbmpc_pipe_set_checked(hbmpc_pipe* pipe, int on);
+ShareErrorCode hbmpc_pipe_run(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_deal(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_finish(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_capture(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_replay(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_sync(hbmpc_pipe* pipe);
+ShareErrorCode hbmpc_pipe_summary(hbmpc_pipe* pipe, hbmpc_recover_summary* summary_out);
+ShareErrorCode hbmpc_pipe_verdict(hbmpc_pipe* pipe, uint32_t verdict_out[2]);
 
 /* ==== a3: RobustShare::compute_shares / NonRobustShare::compute_shares ======================
  * replaces honeybadger/robust_interpolate/robust_interpolate.rs:52-82 and

@@ -319,6 +319,7 @@ extern "C" void hbmpc_destroy(hbmpc_ctx* ctx) {
     delete ctx;
 }
 extern "C" const char* hbmpc_last_error(const hbmpc_ctx*) { return g_err.c_str(); }
+extern "C" FieldKind hbmpc_field_of(const hbmpc_ctx* ctx) { return ctx && is_gold(ctx) ? Goldilocks64 : Bls12_381Fr; }
 extern "C" ShareErrorCode hbmpc_set_field_impl(hbmpc_ctx* ctx, int impl) {
     if (!ctx || (impl != IMPL_U29 && impl != IMPL_SAT32)) return InvalidInput;
     REQ_FR(ctx);

@@ -10,9 +10,13 @@
 //! * `GpuShares`            one library context; batched calls (`compute_shares_batch`, `batch_recover_secret`, ...)
 //! * `GpuRobustShare`       newtype over `RobustShare<Fr>` whose `SecretSharingScheme<Fr>` impl delegates the two
 //!                          scheme functions to the process-wide `GpuShares` and every operator to the inner share
+//! * `GpuPipeline`          a device-resident pipeline of ALL n simulated parties (`hbmpc_pipe_*`: triple generation,
+//!                          fixed-point multiplication, RanSha, RanDouSha, run_preprocessing's triple part) -- what
+//!                          `run_preprocessing` (honeybadger/mod.rs:1239-1413), `TripleGenNode::init_batch`
+//!                          (triple_gen/triple_generation.rs:304-364) and `FPMulNode::init` (fpmul/fpmul.rs:61-110) drive
 //! * `check`                `ShareErrorCode` -> `InterpolateError` / `ShareError`, the inverse of the mapping the
 //!                          reference's C bindings apply (mpc/src/ffi/c_bindings/share/mod.rs:18-37)
-use std::ffi::CStr;
+use std::ffi::{CStr, CString};
 use std::ops::{Add, Mul, Sub};
 use std::sync::{Mutex, OnceLock};
 
@@ -201,6 +205,154 @@ impl GpuShares {
         let rc = unsafe { sys::hbmpc_vandermonde_apply(self.ctx, flat.as_ptr(), g, n, degree, out.as_mut_ptr()) };
         self.check(rc, n)?;
         Ok((0..n).map(|j| out[j * g..(j + 1) * g].iter().map(from_u256).collect()).collect())
+    }
+}
+
+
+// ---- device-resident pipelines (include/hbmpc_hip.h, "device-resident pipelines") -------------------------------------
+/// One `hbmpc_pipe` handle: the call sequencing, the arena layout and the graph-capture rules live in the library.
+/// Buffers are `[party][..]` arrays reached by name (`"a"`, `"b"`, `"r2t"`, `"rt"`, `"c"` for triple generation; see the
+/// header for the other kinds).  `run` only enqueues on the handle's stream; `run_checked` reads the decode summaries back
+/// and returns the error the reference's `?` would.
+pub struct GpuPipeline<'a> {
+    gpu: &'a GpuShares,
+    pipe: *mut sys::HbmpcPipe,
+    owned: bool,
+}
+
+impl Drop for GpuPipeline<'_> {
+    fn drop(&mut self) {
+        if self.owned {
+            unsafe { sys::hbmpc_pipe_destroy(self.pipe) }
+        }
+    }
+}
+
+impl GpuShares {
+    /// a HIP stream of this context's device for the pipelines (graph capture needs a real stream)
+    pub fn stream_create(&self) -> Result<*mut core::ffi::c_void, InterpolateError> {
+        let mut s = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_stream_create(self.ctx, &mut s) };
+        self.check(rc, 0)?;
+        Ok(s)
+    }
+    fn wrap(&self, rc: sys::ShareErrorCode, pipe: *mut sys::HbmpcPipe, n: usize) -> Result<GpuPipeline<'_>, InterpolateError> {
+        self.check(rc, n)?;
+        Ok(GpuPipeline { gpu: self, pipe, owned: true })
+    }
+    /// `TripleGenNode::init_batch` + BatchRecon(2t) + finalize for all n parties (triple_gen/triple_generation.rs:304-364,164-232)
+    pub fn pipe_triplegen(&self, n: usize, t: usize, triples: usize, stream: *mut core::ffi::c_void) -> Result<GpuPipeline<'_>, InterpolateError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_pipe_triplegen_create(self.ctx, n, t, triples, stream, &mut p) };
+        self.wrap(rc, p, n)
+    }
+    /// `FPMulNode::init` = Beaver multiplication + TruncPr for all n parties (fpmul/fpmul.rs:61-110, fpmul/truncpr.rs:185-318)
+    pub fn pipe_fpmul(&self, n: usize, t: usize, pairs: usize, k: usize, m: usize, stream: *mut core::ffi::c_void) -> Result<GpuPipeline<'_>, InterpolateError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_pipe_fpmul_create(self.ctx, n, t, pairs, k, m, 0, stream, &mut p) };
+        self.wrap(rc, p, n)
+    }
+    /// `RanShaNode` for all n parties, `batch` elements per dealer (share_gen/share_gen.rs:232-289,401-454,516-530)
+    pub fn pipe_ransha(&self, n: usize, t: usize, batch: usize, stream: *mut core::ffi::c_void) -> Result<GpuPipeline<'_>, InterpolateError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_pipe_ransha_create(self.ctx, n, t, batch, 0, stream, &mut p) };
+        self.wrap(rc, p, n)
+    }
+    /// `DouShaNode` + `RanDouShaNode` for all n parties (ran_dou_sha/mod.rs:371-449,569-602)
+    pub fn pipe_randousha(&self, n: usize, t: usize, batch: usize, stream: *mut core::ffi::c_void) -> Result<GpuPipeline<'_>, InterpolateError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_pipe_randousha_create(self.ctx, n, t, batch, stream, &mut p) };
+        self.wrap(rc, p, n)
+    }
+    /// `run_preprocessing`'s triple part: RanSha -> a, b; RanDouSha -> r; TripleGen (honeybadger/mod.rs:1239-1393)
+    pub fn pipe_preprocessing(&self, n: usize, t: usize, triples: usize, stream: *mut core::ffi::c_void) -> Result<GpuPipeline<'_>, InterpolateError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_pipe_preprocessing_create(self.ctx, n, t, triples, stream, &mut p) };
+        self.wrap(rc, p, n)
+    }
+}
+
+impl<'a> GpuPipeline<'a> {
+    fn name(name: &str) -> CString {
+        CString::new(name).expect("buffer names have no NUL")
+    }
+    /// a part of a preprocessing pipeline (`"ransha"`, `"randousha"`, `"triplegen"`): borrowed, lives as long as `self`
+    pub fn part(&self, name: &str) -> Result<GpuPipeline<'a>, InterpolateError> {
+        let mut p = std::ptr::null_mut();
+        let rc = unsafe { sys::hbmpc_pipe_part(self.pipe, Self::name(name).as_ptr(), &mut p) };
+        self.gpu.check(rc, 0)?;
+        Ok(GpuPipeline { gpu: self.gpu, pipe: p, owned: false })
+    }
+    /// device pointer and element count of a named buffer (for hosts that fill it with their own device calls)
+    pub fn buffer(&self, name: &str) -> Result<(*mut sys::U256, usize), InterpolateError> {
+        let (mut p, mut n) = (std::ptr::null_mut(), 0usize);
+        let rc = unsafe { sys::hbmpc_pipe_buffer(self.pipe, Self::name(name).as_ptr(), &mut p, &mut n) };
+        self.gpu.check(rc, 0)?;
+        Ok((p as *mut sys::U256, n))
+    }
+    /// `[party][..]` values into a named input buffer
+    pub fn upload(&self, name: &str, values: &[Fr]) -> Result<(), InterpolateError> {
+        let v: Vec<sys::U256> = values.iter().map(to_u256).collect();
+        let rc = unsafe { sys::hbmpc_pipe_upload(self.pipe, Self::name(name).as_ptr(), v.as_ptr() as *const core::ffi::c_void, v.len()) };
+        self.gpu.check(rc, 0)
+    }
+    /// the first `elements` values of a named buffer (synchronises)
+    pub fn download(&self, name: &str, elements: usize) -> Result<Vec<Fr>, InterpolateError> {
+        let mut v = vec![sys::U256::default(); elements];
+        let rc = unsafe { sys::hbmpc_pipe_download(self.pipe, Self::name(name).as_ptr(), v.as_mut_ptr() as *mut core::ffi::c_void, elements) };
+        self.gpu.check(rc, 0)?;
+        Ok(v.iter().map(from_u256).collect())
+    }
+    /// enqueue the whole pipeline on its stream
+    pub fn run(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_set_checked(self.pipe, 0) };
+        self.gpu.check(rc, 0)?;
+        let rc = unsafe { sys::hbmpc_pipe_run(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    /// run and read every decode's summary back: a chunk that fails ends the run with its error, as the reference's `?` does
+    pub fn run_checked(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_set_checked(self.pipe, 1) };
+        self.gpu.check(rc, 0)?;
+        let rc = unsafe { sys::hbmpc_pipe_run(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    /// the two halves of a producer's run: the dealers' `compute_shares`, then everything after their messages have arrived
+    pub fn deal(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_deal(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    pub fn finish(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_finish(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    /// record the call sequence as a HIP graph (after two eager runs); `replay` launches the recording
+    pub fn capture(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_capture(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    pub fn replay(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_replay(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    pub fn sync(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_pipe_sync(self.pipe) };
+        self.gpu.check(rc, 0)
+    }
+    /// the last decode's summary (synchronises)
+    pub fn summary(&self) -> Result<sys::RecoverSummary, InterpolateError> {
+        let mut s = sys::RecoverSummary::default();
+        let rc = unsafe { sys::hbmpc_pipe_summary(self.pipe, &mut s) };
+        self.gpu.check(rc, 0)?;
+        Ok(s)
+    }
+    /// a producer's verdict: (verifier checks that failed, first failing batch element); (0, _) = every verifier says OK
+    /// -- the `Ok` / abort decision of share_gen.rs:516-530 and ran_dou_sha/mod.rs:586-602 for the whole batch
+    pub fn verdict(&self) -> Result<(u32, u32), InterpolateError> {
+        let mut v = [0u32; 2];
+        let rc = unsafe { sys::hbmpc_pipe_verdict(self.pipe, v.as_mut_ptr()) };
+        self.gpu.check(rc, 0)?;
+        Ok((v[0], v[1]))
     }
 }
 

@@ -118,6 +118,77 @@ static int seeded_and_wire(hbmpc_ctx* ctx) {
     return 0;
 }
 
+/* The pipelines behind the C ABI (hbmpc_pipe_*): run_preprocessing's triple part for n = 4, t = 1 from the dealers' polynomials
+ * (honeybadger/mod.rs:1239-1393: RanSha -> a, b; DouSha + RanDouSha -> r; TripleGen), checked with the library's own host calls:
+ * every opened c must equal the opened a times the opened b, the producers' verdicts must be clean, and the same handle
+ * replayed as a HIP graph must give the same bytes. */
+#define PRE_N 4
+#define PRE_T 1
+#define PRE_TRIPLES 6 /* a multiple of 2t + 1, of n - 2t and of t + 1: the producers write straight into TripleGen's arrays */
+static int preprocessing_pipeline(hbmpc_ctx* ctx) {
+    enum { n = PRE_N, t = PRE_T, N = PRE_TRIPLES, Krs = 2 * N / (n - 2 * t), Krd = N / (t + 1) };
+    static U256 co[n * Krs * (t + 1)], ct[n * Krd * (t + 1)], c2t[n * Krd * (2 * t + 1)], a[n * N], b[n * N], c[n * N], c2[n * N];
+    hbmpc_pipe *pre = NULL, *rs = NULL, *rd = NULL, *tg = NULL;
+    hbmpc_recover_summary sm;
+    void* stream = NULL;
+    uint32_t verdict[2] = {9, 9};
+    size_t ids[n], deg[n], i, p, k, nco = 0, elements = 0;
+    void* dev = NULL;
+    for (i = 0; i < n; ++i) ids[i] = i, deg[i] = t;
+    for (i = 0; i < sizeof co / sizeof co[0]; ++i) co[i] = rand_fr();
+    for (i = 0; i < sizeof ct / sizeof ct[0]; ++i) ct[i] = rand_fr();
+    for (i = 0; i < sizeof c2t / sizeof c2t[0]; ++i) c2t[i] = rand_fr();
+    for (k = 0; k < (size_t)n * Krd; ++k) c2t[k * (2 * t + 1)] = ct[k * (t + 1)]; /* the same secret in both sharings */
+    CHECK(hbmpc_stream_create(ctx, &stream) == ShareSuccess);
+    CHECK(hbmpc_pipe_preprocessing_create(ctx, n, t, N, stream, &pre) == ShareSuccess);
+    CHECK(hbmpc_pipe_part(pre, "ransha", &rs) == ShareSuccess && hbmpc_pipe_part(pre, "randousha", &rd) == ShareSuccess &&
+          hbmpc_pipe_part(pre, "triplegen", &tg) == ShareSuccess);
+    CHECK(hbmpc_pipe_part(pre, "nonsense", &tg) == InvalidInput && hbmpc_pipe_part(pre, "triplegen", &tg) == ShareSuccess);
+    CHECK(hbmpc_pipe_buffer(rs, "coeffs", &dev, &elements) == ShareSuccess && dev != NULL && elements == sizeof co / sizeof co[0]);
+    CHECK(hbmpc_pipe_buffer(rs, "no such buffer", &dev, &elements) == InvalidInput);
+    CHECK(hbmpc_pipe_upload(rs, "coeffs", co, sizeof co / sizeof co[0]) == ShareSuccess);
+    CHECK(hbmpc_pipe_upload(rs, "coeffs", co, sizeof co / sizeof co[0] + 1) == InvalidInput); /* beyond the buffer */
+    CHECK(hbmpc_pipe_upload(rd, "coeffs_t", ct, sizeof ct / sizeof ct[0]) == ShareSuccess);
+    CHECK(hbmpc_pipe_upload(rd, "coeffs_2t", c2t, sizeof c2t / sizeof c2t[0]) == ShareSuccess);
+    CHECK(hbmpc_pipe_set_checked(pre, 1) == ShareSuccess && hbmpc_pipe_run(pre) == ShareSuccess);
+    CHECK(hbmpc_pipe_verdict(pre, verdict) == ShareSuccess && verdict[0] == 0);
+    CHECK(hbmpc_pipe_summary(tg, &sm) == ShareSuccess && sm.n_failed == 0);
+    CHECK(hbmpc_pipe_download(tg, "a", a, (size_t)n * N) == ShareSuccess && hbmpc_pipe_download(tg, "b", b, (size_t)n * N) == ShareSuccess &&
+          hbmpc_pipe_download(tg, "c", c, (size_t)n * N) == ShareSuccess);
+    for (i = 0; i < N; ++i) { /* open triple i from the n parties' shares: c = a b */
+        U256 sa[n], sb[n], sc[n], oa, ob, oc, ab, coeffs[t + 1];
+        for (p = 0; p < n; ++p) sa[p] = a[p * N + i], sb[p] = b[p * N + i], sc[p] = c[p * N + i];
+        CHECK(hbmpc_recover_secret(ctx, ids, deg, sa, n, n, t, coeffs, &nco, &oa) == ShareSuccess);
+        CHECK(hbmpc_recover_secret(ctx, ids, deg, sb, n, n, t, coeffs, &nco, &ob) == ShareSuccess);
+        CHECK(hbmpc_recover_secret(ctx, ids, deg, sc, n, n, t, coeffs, &nco, &oc) == ShareSuccess);
+        CHECK(hbmpc_fr_op(ctx, 2, &oa, &ob, 1, &ab) == ShareSuccess && memcmp(&ab, &oc, sizeof ab) == 0);
+    }
+    /* the same handle as a HIP graph: c cleared, replayed, identical */
+    CHECK(hbmpc_pipe_capture(pre) == ShareSuccess);
+    memset(c2, 0, sizeof c2);
+    CHECK(hbmpc_pipe_upload(tg, "c", c2, (size_t)n * N) == ShareSuccess);
+    CHECK(hbmpc_pipe_replay(pre) == ShareSuccess && hbmpc_pipe_sync(pre) == ShareSuccess);
+    CHECK(hbmpc_pipe_download(tg, "c", c2, (size_t)n * N) == ShareSuccess && memcmp(c, c2, sizeof c) == 0);
+    /* a dealer that deals an inconsistent share: RanSha's verifiers must say so (share_gen.rs:516-530) */
+    CHECK(hbmpc_pipe_deal(rs) == ShareSuccess);
+    CHECK(hbmpc_pipe_buffer(rs, "S", &dev, NULL) == ShareSuccess);
+    {
+        U256 one;
+        U256* at = (U256*)dev + (1 * n + 2) * Krs + 1; /* dealer 1's share for recipient 2, batch element 1 */
+        CHECK(hbmpc_memcpy_d2h(ctx, &one, at, sizeof one, stream) == ShareSuccess && hbmpc_stream_sync(ctx, stream) == ShareSuccess);
+        one.data[0] ^= 1;
+        CHECK(hbmpc_memcpy_h2d(ctx, at, &one, sizeof one, stream) == ShareSuccess);
+    }
+    CHECK(hbmpc_pipe_finish(rs) == ShareSuccess && hbmpc_pipe_verdict(rs, verdict) == ShareSuccess && verdict[0] >= 1 && verdict[1] == 1);
+    /* shapes the reference rejects / wrong handle kinds */
+    CHECK(hbmpc_pipe_ransha_create(ctx, 4, 2, 3, 0, stream, &rs) == InvalidInput); /* n <= 2t */
+    CHECK(hbmpc_pipe_triplegen_create(ctx, 4, 1, 4, stream, &rs) == InvalidInput); /* N not a multiple of 2t + 1 */
+    CHECK(hbmpc_pipe_deal(tg) == InvalidInput && hbmpc_pipe_verdict(tg, verdict) == InvalidInput);
+    hbmpc_pipe_destroy(pre);
+    CHECK(hbmpc_stream_destroy(ctx, stream) == ShareSuccess);
+    return 0;
+}
+
 int main(void) {
     hbmpc_ctx* ctx = NULL;
     int bad = 0;
@@ -128,6 +199,7 @@ int main(void) {
     bad += robust_roundtrip(ctx);
     bad += nonrobust_roundtrip(ctx);
     bad += seeded_and_wire(ctx);
+    bad += preprocessing_pipeline(ctx);
     hbmpc_destroy(ctx);
     bad += goldilocks_roundtrip();
     if (bad == 0) printf("C ABI round trips passed (%s)\n", hbmpc_version());

@@ -67,7 +67,7 @@ static void triple_gen(void* stream) {
     tg.run();
     std::vector<U256> c(n * N);
     tg.download(c.data(), tg.c, n * N);
-    CHECK(tg.last_summary(tg.summ).n_failed == 0);
+    CHECK(tg.last_summary().n_failed == 0);
     CHECK(same(open_all(c, n, N, t, t), mul_all(a, b)));  // [c]_t opens to a * b
     tg.capture();
     std::vector<U256> zero(n * N, small(0)), c2(n * N);
@@ -104,7 +104,7 @@ static void fpmul(void* stream) {
     std::vector<U256> z(n * N), out(n * N);
     fp.download(z.data(), fp.z, n * N);
     fp.download(out.data(), fp.out, n * N);
-    CHECK(fp.last_summary(fp.summ).n_failed == 0);
+    CHECK(fp.last_summary().n_failed == 0);
     const std::vector<U256> zo = open_all(z, n, N, t, t), oo = open_all(out, n, N, t, t);
     for (size_t i = 0; i < N; ++i) {
         const uint64_t prod = xs[i] * ys[i];
@@ -135,10 +135,10 @@ static void preprocessing(void* stream, size_t groups) {  // groups = 3: N = 15 
     pre.rd.upload(pre.rd.coeffs_2t, c2t.data(), c2t.size());
     pre.run();
     uint32_t v1[2], v2[2];
-    pre.rs.verdict(pre.rs.bad, v1);
-    pre.rd.verdict(pre.rd.bad, v2);
+    pre.rs.verdict(v1);
+    pre.rd.verdict(v2);
     CHECK(v1[0] == 0 && v2[0] == 0);
-    CHECK(pre.tg.last_summary(pre.tg.summ).n_failed == 0);
+    CHECK(pre.tg.last_summary().n_failed == 0);
     std::vector<U256> a(n * N), b(n * N), c(n * N);
     pre.tg.download(a.data(), pre.tg.a, n * N);
     pre.tg.download(b.data(), pre.tg.b, n * N);
@@ -151,7 +151,7 @@ static void preprocessing(void* stream, size_t groups) {  // groups = 3: N = 15 
     one[0].data[0] ^= 1;
     pre.rs.upload(pre.rs.S + (3 * n + 1) * Krs + 2, one.data(), 1);
     pre.rs.finish();
-    pre.rs.verdict(pre.rs.bad, v1);
+    pre.rs.verdict(v1);
     CHECK(v1[0] >= 1 && v1[1] == 2);
 }
 
