@@ -332,6 +332,16 @@ ShareErrorCode hbmpc_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t
 ShareErrorCode hbmpc_dev_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals_dev,
                                            size_t row_stride, size_t G, size_t n, U256* coeffs_out_dev,
                                            uint32_t* degree_out_dev, void* stream);
+/* What the RanDouSha verifier keeps of an interpolation (ran_dou_sha/mod.rs:586-589: the degree of each of its two polynomials
+ * and whether their constant terms agree): c0_out[G] = coefficient 0, degree_out[G] = DensePolynomial::degree().  Through all
+ * n shares of an 8- or 16-point domain the kernel writes just these (36 bytes per column instead of 32 S); other shapes
+ * interpolate into tmp_coeffs_dev[G][S] (required) and extract them.  hbmpc_dev_check_double_share_c0 is the test on two such
+ * pairs: bad[0] += columns with degree_t != t, degree_2t != 2 t or c0_t != c0_2t, bad[1] = min(first such column). */
+ShareErrorCode hbmpc_dev_batch_interpolate_c0(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals_dev, size_t row_stride,
+                                              size_t G, size_t n, U256* tmp_coeffs_dev, U256* c0_out_dev, uint32_t* degree_out_dev,
+                                              void* stream);
+ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
+                                               const uint32_t* degree_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream);
 
 /* ---- layout and verdict steps of the preprocessing producers (RanSha, DouSha, RanDouSha; either field: the element
  * size follows the context) -----------------------------------------------------------------------------------------
@@ -479,6 +489,27 @@ ShareErrorCode hbmpc_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const U256* x_ro
                                                 size_t d, U256* tmp_dev, U256* y_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
                                                    size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, void* stream);
+/* The same mixing step with the parties' OUTPUT rows written as the lists the reference returns (share_gen.rs:199-203: rows
+ * 2t .. n-1, ran_dou_sha/mod.rs:314-331: rows 0 .. t -- per party in the order [batch element k][row]), so that no pass copies
+ * them out of y afterwards.  The G = parties * K chunks are (party j, batch element k) = g / K, g % K.  Output rows
+ * [list_row0, list_row0 + list_rows) of chunk (j, k) go to
+ *     slices[s].dst_dev + (j * party_stride + (k - k0) * list_rows + (row - list_row0)) elements
+ * for the slice s whose [k0, k0 + count) holds k (at most two slices, ascending and disjoint: a consumer that wants the first
+ * N of a party's list in one array and the next N in another -- TripleGen's a and b -- names both; batch elements no slice
+ * holds are not written).  The other rows go to y_out[row][G] as above; the list rows of y_out are unspecified.  Large Fr batches
+ * on domains of 8 and 16 points write the lists from the kernel that computes them; every other shape (and
+ * hbmpc_set_producer_fusion(ctx, 0)) computes all of y_out and copies the slices out with hbmpc_dev_transpose -- same bytes. */
+typedef struct {
+    void* dst_dev;
+    size_t party_stride; /* elements between the lists of consecutive parties */
+    size_t k0, count;    /* batch elements [k0, k0 + count) of every party */
+} hbmpc_list_slice;
+ShareErrorCode hbmpc_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                      size_t d, U256* tmp_dev, U256* y_out_dev, size_t list_row0, size_t list_rows, size_t K,
+                                                      const hbmpc_list_slice* slices, size_t n_slices, void* stream);
+ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                         size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, size_t list_row0, size_t list_rows,
+                                                         size_t K, const hbmpc_list_slice* slices, size_t n_slices, void* stream);
 /* In-place wire path -- no pack / unpack pass.  A payload that starts 8 bytes before a 32-byte boundary has its
  * elements 32-byte aligned, so the encode kernel writes the payload bodies itself and the decode reads them where
  * they arrived:
@@ -565,6 +596,9 @@ ShareErrorCode hbmpc_gl_dev_batch_recover_strided(hbmpc_ctx* ctx, const size_t* 
                                                   uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
 ShareErrorCode hbmpc_gl_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals, size_t G,
                                           size_t n, uint64_t* coeffs_out, uint32_t* degree_out);
+ShareErrorCode hbmpc_gl_dev_batch_interpolate_c0(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals_dev, size_t row_stride,
+                                                 size_t G, size_t n, uint64_t* tmp_coeffs_dev, uint64_t* c0_out_dev,
+                                                 uint32_t* degree_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals_dev,
                                               size_t row_stride, size_t G, size_t n, uint64_t* coeffs_out_dev,
                                               uint32_t* degree_out_dev, void* stream);
@@ -651,6 +685,9 @@ ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t min_chunks)
  *   on = 0: everything up front, as rounds 1 and 2 did (A/B aid).
  * Inside a graph capture nothing can be looked at and the tables must exist.  Results are identical in every mode. */
 ShareErrorCode hbmpc_set_lazy_fallback_tables(hbmpc_ctx* ctx, int on);
+/* The producers' fused steps (the mixing step writes the parties' lists itself; the RanDouSha verifier's interpolation keeps
+ * only c0 and the degree): on (default) / off = every row into y and separate copy / test passes (A/B aid; same bytes). */
+ShareErrorCode hbmpc_set_producer_fusion(hbmpc_ctx* ctx, int on);
 /* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have
  * arrived (batch_recon.rs:371-389) -- has no OEC round: a chunk that fails the verification can only fail
  * (DecodingError, robust_interpolate.rs:625).  Such a call is ONE kernel launch: the decode kernel writes the failure

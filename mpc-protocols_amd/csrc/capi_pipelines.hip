@@ -46,6 +46,16 @@ struct Calls {
         return gl ? hbmpc_gl_dev_vandermonde_apply_rows(c, (const uint64_t*)x, stride, G, n, d, (uint64_t*)tmp, (uint64_t*)y, s)
                   : hbmpc_dev_vandermonde_apply_rows(c, (const U256*)x, stride, G, n, d, (U256*)tmp, (U256*)y, s);
     }
+    ShareErrorCode apply_rows_lists(hbmpc_ctx* c, const void* x, size_t stride, size_t G, size_t n, size_t d, void* tmp, void* y, size_t row0,
+                                    size_t rows, size_t K, const hbmpc_list_slice* sl, size_t nsl, void* s) const {
+        return gl ? hbmpc_gl_dev_vandermonde_apply_rows_lists(c, (const uint64_t*)x, stride, G, n, d, (uint64_t*)tmp, (uint64_t*)y, row0, rows, K, sl, nsl, s)
+                  : hbmpc_dev_vandermonde_apply_rows_lists(c, (const U256*)x, stride, G, n, d, (U256*)tmp, (U256*)y, row0, rows, K, sl, nsl, s);
+    }
+    ShareErrorCode interpolate_c0(hbmpc_ctx* c, const size_t* ids, size_t S, const void* ev, size_t stride, size_t G, size_t n, void* tmp,
+                                  void* c0, uint32_t* deg, void* s) const {
+        return gl ? hbmpc_gl_dev_batch_interpolate_c0(c, ids, S, (const uint64_t*)ev, stride, G, n, (uint64_t*)tmp, (uint64_t*)c0, deg, s)
+                  : hbmpc_dev_batch_interpolate_c0(c, ids, S, (const U256*)ev, stride, G, n, (U256*)tmp, (U256*)c0, deg, s);
+    }
     ShareErrorCode recover_strided(hbmpc_ctx* c, const size_t* ids, size_t S, const void* ev, size_t stride, size_t G, size_t n, size_t d,
                                    size_t t, int p0, void* out, uint32_t* nco, uint8_t* st, hbmpc_recover_summary* sm, void* s) const {
         return gl ? hbmpc_gl_dev_batch_recover_strided(c, ids, S, (const uint64_t*)ev, stride, G, n, d, t, p0, (uint64_t*)out, nco, st, sm, s)
@@ -77,12 +87,9 @@ struct Buffer {
     unsigned char* p;
     size_t elements;  // of the context's field (status / verdict buffers: bytes)
 };
-// where a slice of every party's output list goes instead of the producer's own buffer: batch elements [k0, k0 + count) of
-// party p to dst + p * stride (elements)
-struct Slice {
-    unsigned char* dst;
-    size_t stride, k0, count;
-};
+// where a slice of every party's output list goes instead of the producer's own buffer: hbmpc_list_slice {dst, party stride,
+// k0, count} = batch elements [k0, k0 + count) of party p to dst + p * stride (elements)
+using Slice = hbmpc_list_slice;
 
 }  // namespace
 
@@ -233,10 +240,12 @@ struct Producer : hbmpc_pipe {
         for (size_t p = 0; p < n; ++p)  // dealer p: compute_shares of its K polynomials
             PL(f.compute_shares(ctx, coeffs + p * K * (deg + 1) * f.eb, K, n, deg, S + p * n * K * f.eb, stream));
     }
-    void mix(const unsigned char* S, unsigned char* x, unsigned char* y) {
-        // the share of dealer p for (recipient, element) is row p of S: the n x n map reads the dealers' outputs in place; x is
-        // the workspace of the shapes that have to be transposed first
-        PL(f.apply_rows(ctx, S, n * K, n * K, n, n - 1, x, y, stream));
+    // The share of dealer p for (recipient, element) is row p of S: the n x n map reads the dealers' outputs in place (x is the
+    // workspace of the shapes that have to be transposed first).  Rows [row0, row0 + rows) of the result are the parties' OUTPUT:
+    // they are written as the per-party lists [k][row] the reference returns, where `lists` says; the other rows -- what the
+    // parties send the verifiers -- to y[row][party, k]
+    void mix(const unsigned char* S, unsigned char* x, unsigned char* y, size_t row0, size_t rows, const std::vector<Slice>& lists) {
+        PL(f.apply_rows_lists(ctx, S, n * K, n * K, n, n - 1, x, y, row0, rows, K, lists.data(), lists.size(), stream));
     }
     void run() override {
         deal();
@@ -275,16 +284,13 @@ struct RanSha : Producer {
     }
     void deal() override { deal_one(coeffs, t, S); }
     void finish() override {  // everything after the dealers' messages have arrived
-        mix(S, x, y);
+        // rows 2t .. n - 1 of every batch element are the output, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
+        mix(S, x, y, 2 * t, n - 2 * t, split.empty() ? std::vector<Slice>{{out, nout, 0, K}} : split);
         clear_bad();
         for (size_t i = 0; i < 2 * t; ++i) {  // verifier i: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530)
             PL(f.recover_strided(ctx, ids.data(), ids.size(), y + i * n * K * f.eb, K, K, n, t, t, 0, poly, nullptr, status, summ, stream));
             PL(hbmpc_dev_check_degree(ctx, poly, status, K, t + 1, t, bad, stream));
         }
-        // rows 2t .. n - 1 of every batch element, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
-        const std::vector<Slice> whole = {{out, nout, 0, K}};
-        for (const Slice& sl : split.empty() ? whole : split)
-            PL(hbmpc_dev_transpose(ctx, y + (2 * t * n * K + sl.k0) * f.eb, n - 2 * t, sl.count, n * K, sl.dst, n - 2 * t, n, K, sl.stride, stream));
     }
 };
 
@@ -292,7 +298,7 @@ struct RanSha : Producer {
 // interpolates both polynomials through ALL n shares (ran_dou_sha/mod.rs:557-602)
 struct RanDouSha : Producer {
     size_t nout;
-    unsigned char *coeffs_t, *coeffs_2t, *S_t, *S_2t, *x, *y_t, *y_2t, *poly_t, *poly_2t, *out_t, *out_2t;
+    unsigned char *coeffs_t, *coeffs_2t, *S_t, *S_2t, *x, *y_t, *y_2t, *poly, *c0_t, *c0_2t, *out_t, *out_2t;
     uint32_t *deg_t, *deg_2t;
     std::vector<size_t> ids;
     std::vector<Slice> split_t, split_2t;
@@ -301,11 +307,12 @@ struct RanDouSha : Producer {
         return (t + 1) * K;
     }
     RanDouSha(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
-        arena((n * K * (3 * t + 2) + 5 * n * n * K + 2 * K * n + 2 * n * nout) * f.eb + 8 * K + (1 << 14));
+        arena((n * K * (3 * t + 2) + 5 * n * n * K + K * n + 2 * K + 2 * n * nout) * f.eb + 8 * K + (1 << 14));
         coeffs_t = take("coeffs_t", n * K * (t + 1)), coeffs_2t = take("coeffs_2t", n * K * (2 * t + 1));
         S_t = take("S_t", n * n * K), S_2t = take("S_2t", n * n * K);
         x = take("x", n * n * K), y_t = take("y_t", n * n * K), y_2t = take("y_2t", n * n * K);
-        poly_t = take("poly_t", K * n), poly_2t = take("poly_2t", K * n);
+        poly = take("poly", K * n);  // workspace of the verifier interpolations that have no c0-only kernel
+        c0_t = take("c0_t", K), c0_2t = take("c0_2t", K);
         deg_t = reinterpret_cast<uint32_t*>(take_bytes("deg_t", 4 * K, K)), deg_2t = reinterpret_cast<uint32_t*>(take_bytes("deg_2t", 4 * K, K));
         bad = reinterpret_cast<uint32_t*>(take_bytes("bad", 64, 16));
         out_t = take("out_t", n * nout), out_2t = take("out_2t", n * nout);  // [party][K][t + 1]  (ran_dou_sha/mod.rs:314-331)
@@ -316,20 +323,16 @@ struct RanDouSha : Producer {
         deal_one(coeffs_2t, 2 * t, S_2t);
     }
     void finish() override {
-        mix(S_t, x, y_t);    // RanDouShaNode::init_batch step 1
-        mix(S_2t, x, y_2t);  // step 2
+        // RanDouShaNode::init_batch steps 1, 2, 4-5: rows 0 .. t are the output, per party in the order [k][i]  (ran_dou_sha/mod.rs:314-331)
+        mix(S_t, x, y_t, 0, t + 1, split_t.empty() ? std::vector<Slice>{{out_t, nout, 0, K}} : split_t);
+        mix(S_2t, x, y_2t, 0, t + 1, split_2t.empty() ? std::vector<Slice>{{out_2t, nout, 0, K}} : split_2t);
         clear_bad();
-        for (size_t i = t + 1; i < n; ++i) {  // step 3: verifier i
-            PL(f.interpolate(ctx, ids.data(), n, y_t + i * n * K * f.eb, K, K, n, poly_t, nullptr, stream));
-            PL(f.interpolate(ctx, ids.data(), n, y_2t + i * n * K * f.eb, K, K, n, poly_2t, nullptr, stream));
-            PL(hbmpc_dev_check_double_share(ctx, poly_t, poly_2t, K, n, t, bad, stream));
+        for (size_t i = t + 1; i < n; ++i) {  // step 3: verifier i interpolates both sharings through all n shares and tests the
+                                              // degrees and the constant terms (:586-602) -- it keeps nothing else of them
+            PL(f.interpolate_c0(ctx, ids.data(), n, y_t + i * n * K * f.eb, K, K, n, poly, c0_t, deg_t, stream));
+            PL(f.interpolate_c0(ctx, ids.data(), n, y_2t + i * n * K * f.eb, K, K, n, poly, c0_2t, deg_2t, stream));
+            PL(hbmpc_dev_check_double_share_c0(ctx, c0_t, deg_t, c0_2t, deg_2t, K, t, bad, stream));
         }
-        // steps 4-5: rows 0 .. t, per party in the order [k][i]  (ran_dou_sha/mod.rs:314-331)
-        const std::vector<Slice> whole_t = {{out_t, nout, 0, K}}, whole_2t = {{out_2t, nout, 0, K}};
-        for (const Slice& sl : split_t.empty() ? whole_t : split_t)
-            PL(hbmpc_dev_transpose(ctx, y_t + sl.k0 * f.eb, t + 1, sl.count, n * K, sl.dst, t + 1, n, K, sl.stride, stream));
-        for (const Slice& sl : split_2t.empty() ? whole_2t : split_2t)
-            PL(hbmpc_dev_transpose(ctx, y_2t + sl.k0 * f.eb, t + 1, sl.count, n * K, sl.dst, t + 1, n, K, sl.stride, stream));
     }
 };
 
@@ -352,9 +355,9 @@ struct Preprocessing : hbmpc_pipe {
         in_place = N % (n - 2 * t) == 0 && N % (t + 1) == 0;
         if (in_place) {
             const size_t k1 = N / (n - 2 * t), k2 = N / (t + 1);
-            rs->split = {{tg->a, N, 0, k1}, {tg->b, N, k1, k1}};
-            rd->split_t = {{tg->rt, N, 0, k2}};
-            rd->split_2t = {{tg->r2t, N, 0, k2}};
+            rs->split = {Slice{tg->a, N, 0, k1}, Slice{tg->b, N, k1, k1}};
+            rd->split_t = {Slice{tg->rt, N, 0, k2}};
+            rd->split_2t = {Slice{tg->r2t, N, 0, k2}};
         }
         summ = tg->summ;
     }

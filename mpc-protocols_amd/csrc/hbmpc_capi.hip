@@ -62,6 +62,7 @@ struct hbmpc_ctx {
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
     int lazy_fallback_tables = 1;                  // a new sender set's OEC / Gao and second-chance tables are built when a chunk needs them: 1 = host-pointer calls, 2 = all
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
+    bool list_rows_in_kernel = true;               // the producers' mixing step writes the parties' lists itself (k_mfma_bfly<.., LISTS>)
     bool mfma_bfly = true;                         // large encodes take the domain points in pairs (kernels_mfma_bfly.hpp)
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
     size_t mfma_min_gold = 4096;                   // Goldilocks encodes (tiny tables, one workgroup kind): from this many chunks
@@ -342,6 +343,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
     }
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_set_producer_fusion(hbmpc_ctx* ctx, int on) {  // either field
+    if (!ctx) return InvalidInput;
+    ctx->list_rows_in_kernel = on != 0;
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_set_lazy_fallback_tables(hbmpc_ctx* ctx, int on) {  // either field
     if (!ctx) return InvalidInput;
     if (on < 0 || on > 2) return InvalidInput;
@@ -559,8 +565,15 @@ extern "C" void hbmpc_graph_destroy(hbmpc_graph* graph) {
 // ---- a3 / a5: evaluation on the domain ---------------------------------------------------------
 // apply_vandermonde / compute_shares as int8 MFMA tiles (kernels_mfma.hpp): row j of the table is (alpha_j^k)_k
 // x_row_stride != 0: x is given as d + 1 ROWS of G elements, x_row_stride elements apart (the point-pair kernel only)
+// lists (the producers' mixing step, MfmaRowsArgs::list): only the point-pair kernel writes them; with lists set the call
+// returns false unless that kernel ran
+struct ListSpec {
+    size_t row0, rows, K;
+    const hbmpc_list_slice* slices;
+    size_t n_slices;
+};
 static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t dp1, EvalOut y, hipStream_t s,
-                          ShareErrorCode* rc_out, size_t x_row_stride = 0) {
+                          ShareErrorCode* rc_out, size_t x_row_stride = 0, const ListSpec* lists = nullptr) {
     *rc_out = ShareSuccess;
     const size_t rowb = mf_row_bytes(dp1);
     mf::MfmaRowsArgs a;
@@ -616,6 +629,16 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
                 b.in_chunk_major = 0, b.row_stride = x_row_stride;
                 for (size_t i = 0; i < dp1; ++i) b.rows.set(i, (unsigned)i);
             }
+            if (lists) {
+                b.list_row0 = (int)lists->row0, b.list_rows = (int)lists->rows, b.list_K = (uint32_t)lists->K;
+                for (size_t k = 0; k < 2; ++k) {
+                    const bool have = k < lists->n_slices;
+                    b.list[k].dst = have ? (uint8_t*)lists->slices[k].dst_dev : nullptr;
+                    b.list[k].stride = have ? lists->slices[k].party_stride : 0;
+                    b.list[k].k0 = have ? (uint32_t)lists->slices[k].k0 : 0u;
+                    b.list[k].count = have ? (uint32_t)lists->slices[k].count : 0u;
+                }
+            }
             for (unsigned p = 0; p < y.parties && ok; ++p) {  // party-batched calls: one launch per party
                 b.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
                 b.out = (uint8_t*)y.y + (size_t)p * n * b.out_stride * 32;
@@ -626,7 +649,7 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
             if (ok) return true;
         }
     }
-    if (!plain_ok) return false;
+    if (!plain_ok || lists) return false;
     const uint32_t* tab;
     *rc_out = get_table(ctx, key("mfvand", {n, dp1}, ctx->impl), [&] { return build_mfma_table(vandermonde(), dp1); }, &tab);
     if (*rc_out != ShareSuccess) return true;
@@ -1590,30 +1613,60 @@ extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_strided(hbmpc_ctx* ctx,
 // x given as d + 1 rows (see include/hbmpc_hip.h): the point-pair matrix-core kernel reads them in place; every other
 // shape goes through the workspace (transpose, then the chunk-major encode)
 static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x_row_stride, size_t G, size_t n, size_t d, void* tmp,
-                                    void* y, void* stream) {
+                                    void* y, void* stream, const ListSpec* lists = nullptr) {
     if (!ctx) return InvalidInput;
     if (n <= d) return fail(ctx, InvalidInput, "number of shares must be greater than the degree");
     if (n == 0 || n > ((size_t)1 << 32)) return fail(ctx, NoSuitableDomain, "no radix-2 domain of that size");
     if (n > (1u << 20) || d > (1u << 20)) return fail(ctx, InvalidInput, "n, d beyond the supported range");
     if (x_row_stride < G) return fail(ctx, InvalidInput, "input row stride must be >= G");
+    if (lists) {
+        if (lists->rows == 0 || lists->row0 + lists->rows > n || lists->K == 0 || G % lists->K != 0 || lists->n_slices == 0 || lists->n_slices > 2 ||
+            !lists->slices)
+            return fail(ctx, InvalidInput, "list rows / slices out of range");
+        for (size_t k = 0; k < lists->n_slices; ++k) {
+            const hbmpc_list_slice& sl = lists->slices[k];
+            if (!sl.dst_dev || sl.count == 0 || sl.k0 + sl.count > lists->K || sl.party_stride < sl.count * lists->rows)
+                return fail(ctx, InvalidInput, "list slice out of range");
+        }
+        if (lists->n_slices == 2 && lists->slices[0].k0 + lists->slices[0].count > lists->slices[1].k0)
+            return fail(ctx, InvalidInput, "list slices must be in ascending, disjoint ranges of batch elements");
+    }
     if (G == 0) return ShareSuccess;
     if (!x_rows || !y) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
     const size_t size = domain_size(n), dp1 = d + 1;
     ShareErrorCode rc_mf = ShareSuccess;
-    if (ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && dp1 >= 2 && dp1 <= MF_BFLY_MAX_M && size >= 8 &&
-        n <= 255 && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 && G * 32 < ((size_t)1 << 32) &&
-        try_mfma_eval(ctx, (const uint32_t*)x_rows, G, n, dp1, EvalOut{(uint32_t*)y, 0, 1}, s, &rc_mf, x_row_stride)) {
+    const bool mf_shape = ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && dp1 >= 2 && dp1 <= MF_BFLY_MAX_M &&
+                          size >= 8 && n <= 255 && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 && G * 32 < ((size_t)1 << 32);
+    // the list rows straight from the kernel that computes them (k_mfma_bfly<.., LISTS>): one role, G < 2^32 chunks
+    if (lists && mf_shape && ctx->list_rows_in_kernel && try_mfma_eval(ctx, (const uint32_t*)x_rows, G, n, dp1, EvalOut{(uint32_t*)y, 0, 1}, s, &rc_mf, x_row_stride, lists)) {
         if (rc_mf != ShareSuccess) return rc_mf;
         HIP_TRY(ctx, hipGetLastError());
         return ShareSuccess;
+    }
+    auto copy_lists = [&]() -> ShareErrorCode {  // every row is in y[row][G]: the list rows are copied out per slice
+        if (!lists) return ShareSuccess;
+        const size_t parties = G / lists->K;
+        for (size_t k = 0; k < lists->n_slices; ++k) {
+            const hbmpc_list_slice& sl = lists->slices[k];
+            const ShareErrorCode rc = hbmpc_dev_transpose(ctx, (const uint8_t*)y + (lists->row0 * G + sl.k0) * ebytes(ctx), lists->rows, sl.count, G,
+                                                          sl.dst_dev, lists->rows, parties, lists->K, sl.party_stride, stream);
+            if (rc != ShareSuccess) return rc;
+        }
+        return ShareSuccess;
+    };
+    if (mf_shape && try_mfma_eval(ctx, (const uint32_t*)x_rows, G, n, dp1, EvalOut{(uint32_t*)y, 0, 1}, s, &rc_mf, x_row_stride)) {
+        if (rc_mf != ShareSuccess) return rc_mf;
+        HIP_TRY(ctx, hipGetLastError());
+        return copy_lists();
     }
     if (!tmp) return fail(ctx, InvalidInput, "no kernel reads this shape from rows: pass a workspace of G * (d + 1) elements");
     if ((dp1 + 15) / 16 > 65535) return fail(ctx, InvalidInput, "d beyond the launch grid");
     launch_transpose(is_gold(ctx) ? 1 : 4, (const uint64_t*)x_rows, dp1, G, x_row_stride, (uint64_t*)tmp, dp1, 1, 0, 0, s);
     HIP_TRY(ctx, hipGetLastError());
-    return eval_dev(ctx, tmp, G, n, d, y, stream);
+    const ShareErrorCode rc = eval_dev(ctx, tmp, G, n, d, y, stream);
+    return rc != ShareSuccess ? rc : copy_lists();
 }
 extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
                                                            size_t d, U256* tmp_dev, U256* y_out_dev, void* stream) {
@@ -1624,6 +1677,24 @@ extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, co
                                                               size_t n, size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, void* stream) {
     REQ_GL(ctx);
     return eval_rows_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, stream);
+}
+static ShareErrorCode eval_rows_lists_any(hbmpc_ctx* ctx, const void* x_rows, size_t x_row_stride, size_t G, size_t n, size_t d, void* tmp, void* y,
+                                          size_t list_row0, size_t list_rows, size_t K, const hbmpc_list_slice* slices, size_t n_slices, void* stream) {
+    const ListSpec ls{list_row0, list_rows, K, slices, n_slices};
+    return eval_rows_any(ctx, x_rows, x_row_stride, G, n, d, tmp, y, stream, &ls);
+}
+extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                                 size_t d, U256* tmp_dev, U256* y_out_dev, size_t list_row0, size_t list_rows,
+                                                                 size_t K, const hbmpc_list_slice* slices, size_t n_slices, void* stream) {
+    REQ_FR(ctx);
+    return eval_rows_lists_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, list_row0, list_rows, K, slices, n_slices, stream);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G,
+                                                                    size_t n, size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, size_t list_row0,
+                                                                    size_t list_rows, size_t K, const hbmpc_list_slice* slices, size_t n_slices,
+                                                                    void* stream) {
+    REQ_GL(ctx);
+    return eval_rows_lists_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, list_row0, list_rows, K, slices, n_slices, stream);
 }
 static ShareErrorCode encode_fvec_any(hbmpc_ctx* ctx, const void* x_dev, size_t G, size_t n, size_t d, void* payloads_dev,
                                       size_t payload_stride_bytes, void* stream) {
@@ -1740,6 +1811,16 @@ extern "C" ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const voi
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
     if (G) launch_check_double(is_gold(ctx) ? 1 : 4, (const uint64_t*)coeffs_t_dev, (const uint64_t*)coeffs_2t_dev, G, (int)m, (int)t, bad_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
+                                                          const uint32_t* degree_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!bad_dev || (G && (!c0_t_dev || !c0_2t_dev || !degree_t_dev || !degree_2t_dev))) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (G) launch_check_double_c0(is_gold(ctx) ? 1 : 4, (const uint64_t*)c0_t_dev, degree_t_dev, (const uint64_t*)c0_2t_dev, degree_2t_dev, G, (int)t, bad_dev, s);
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }

@@ -225,5 +225,32 @@ __global__ __launch_bounds__(256) void k_check_double(const uint64_t* __restrict
         atomicMin(bad + 1, (uint32_t)g);
     }
 }
+// the same tests from what the interpolation kernels leave when the coefficients are not needed: the constant terms c0[G] and the
+// degrees[G] of the two polynomials of every column (hbmpc_dev_batch_interpolate_c0)
+template <int W>
+__global__ __launch_bounds__(256) void k_check_double_c0(const uint64_t* __restrict__ c0t, const uint32_t* __restrict__ degt,
+                                                         const uint64_t* __restrict__ c02t, const uint32_t* __restrict__ deg2t, size_t G, int t,
+                                                         uint32_t* __restrict__ bad) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool wrong = false;
+    if (g < G) {
+        wrong = degt[g] != (uint32_t)t || deg2t[g] != (uint32_t)(2 * t);
+#pragma unroll
+        for (int w = 0; w < W; ++w) wrong |= c0t[g * W + w] != c02t[g * W + w];
+    }
+    const unsigned long long mask = __ballot(wrong);
+    if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
+        atomicAdd(bad, (uint32_t)__popcll(mask));
+        atomicMin(bad + 1, (uint32_t)g);
+    }
+}
+// c0[g] = coeffs[g][0] of chunk-major coefficient rows (the shapes without a fused kernel)
+template <int W>
+__global__ __launch_bounds__(256) void k_take_c0(const uint64_t* __restrict__ coeffs, size_t G, int m, uint64_t* __restrict__ c0) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+#pragma unroll
+    for (int w = 0; w < W; ++w) c0[g * W + w] = coeffs[g * (size_t)m * W + w];
+}
 
 }  // namespace hbmpc

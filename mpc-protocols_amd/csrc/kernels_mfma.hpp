@@ -231,6 +231,20 @@ struct MfmaRowsArgs {
     const uint8_t* in_b;
     const uint8_t* in_r;
     int parties;
+    // kernels_mfma_bfly.hpp, DEG instances: only output rows below store_rows are stored (0: all) -- the degree still looks at every
+    // coefficient, so store_rows = 1 with out_stride = 1 leaves c_0[G] and degree[G] (the RanDouSha verifier's two tests)
+    int store_rows;
+    // kernels_mfma_bfly.hpp: the producers' mixing step writes the parties' OUTPUT rows in the reference's list order.  Output rows
+    // [list_row0, list_row0 + list_rows) of chunk g = j list_K + k (party j, batch element k) go, 32 bytes each, to
+    //   list[s].dst + ((j list[s].stride + (k - list[s].k0) list_rows + (row - list_row0)) * 32,   s: the slice whose [k0, k0 + count) holds k
+    // (share_gen.rs:199-203, ran_dou_sha/mod.rs:314-331: per party [k][row]); list_rows = 0: every row is party-major
+    int list_row0, list_rows;
+    uint32_t list_K;
+    struct ListSlice {
+        uint8_t* dst;
+        uint64_t stride;  // elements between the lists of consecutive parties
+        uint32_t k0, count;
+    } list[2];
 };
 
 // NR > 0: every role of the launch has at most NR rows and the row loop is unrolled NR times with a compile-time trip

@@ -37,8 +37,10 @@ constexpr int MF_BFLY_BIAS = 256;
 // or the LDS.  The tile index then runs over parties x tiles (x[P][G][M] -> y[P][n][G]).
 // DEG: the outputs of a chunk are the coefficients of a polynomial (out chunk-major, one role) and a.ncoeffs[g] receives its
 // degree -- the index of the highest nonzero coefficient, 0 for the zero polynomial (DensePolynomial::degree(), what the
-// RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it.
-template <int M, int WAVES, int NP = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false>
+// RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it; with
+// a.store_rows = 1 only c_0 is stored (the verifier's other test compares the constant terms of its two polynomials).
+// LISTS: the producers' mixing step with the parties' output rows written in list order (MfmaRowsArgs::list).
+template <int M, int WAVES, int NP = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false, bool LISTS = false>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     static_assert(M >= 2 && M <= 16, "digit sums must stay below 0xff0000 (tables_mfma.hpp: proved per table for M = 16)");
     constexpr int ROWB = M * 1024 + MF_BFLY_BIAS;
@@ -89,7 +91,13 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         const size_t b = a.out_party_major ? a.G * 32 : a.G * a.out_stride * 32;
         return b < 0xffffffe0ull ? b : 0xffffffe0ull;
     }());
-    auto store_row = [&](uint8_t* out, uint32_t k, bool exists, bool live, uint32_t qo, const uint32_t (&Rw)[4]) {
+    // sc: this lane's 16 bytes of list row 0 of its chunk (0: the chunk has no list destination), see MfmaRowsArgs::list
+    auto store_row = [&](uint8_t* out, uint32_t k, bool exists, bool live, uint32_t qo, const uint32_t (&Rw)[4], uint64_t sc) {
+        if (LISTS && k - (uint32_t)a.list_row0 < (uint32_t)a.list_rows) {  // wave-uniform
+            if (exists && sc != 0) *reinterpret_cast<uint4*>(sc + (uint64_t)(k - (uint32_t)a.list_row0) * 32) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
+            return;
+        }
+        if (DEG && a.store_rows != 0 && k >= (uint32_t)a.store_rows) exists = false;
         uint8_t* qb = a.out_party_major ? out + (size_t)k * a.out_stride * 32 : out + (size_t)k * 32;  // wave-uniform
         if constexpr (STATIC) {
             v4i val;
@@ -105,6 +113,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         const bool live = gi < a.G;
         const uint32_t g = (uint32_t)(live ? gi : a.G - 1);
         const uint32_t qo = g * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
+        uint64_t sc = 0;
+        if (LISTS && live) {
+            const uint32_t j = g / a.list_K, kk = g - j * a.list_K;
+            const int s = kk - a.list[0].k0 < a.list[0].count ? 0 : kk - a.list[1].k0 < a.list[1].count ? 1 : -1;
+            if (s >= 0) {
+                const MfmaRowsArgs::ListSlice sl = s ? a.list[1] : a.list[0];
+                sc = (uint64_t)sl.dst + ((uint64_t)j * sl.stride + (uint64_t)(kk - sl.k0) * (uint32_t)a.list_rows) * 32 + 16u * h;
+            }
+        }
         [[maybe_unused]] uint32_t degree = 0;
         [[maybe_unused]] auto note_degree = [&](uint32_t k, bool exists, const uint32_t (&Rw)[4]) {
             const uint32_t any = Rw[0] | Rw[1] | Rw[2] | Rw[3];
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] + pt[2 * j + 1]) * H.k16 + (pe[2 * j] + pt[2 * j]);
                 reduce_words(T, Rw, H);
-                store_row(out, k32, true, live, qo, Rw);
+                store_row(out, k32, true, live, qo, Rw, sc);
                 if constexpr (DEG) note_degree(k32, true, Rw);
             }
             const bool partner = (int)k32 + a.half < a.nout;
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[j] = (uint64_t)(pe[2 * j + 1] - pt[2 * j + 1]) * H.k16 + (pe[2 * j] - pt[2 * j]);
                 reduce_words(T, Rw, H);
-                store_row(out, k32 + (uint32_t)a.half, partner, live, qo, Rw);
+                store_row(out, k32 + (uint32_t)a.half, partner, live, qo, Rw, sc);
                 if constexpr (DEG) note_degree(k32 + (uint32_t)a.half, partner, Rw);
             }
         }

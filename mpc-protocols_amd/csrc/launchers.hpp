@@ -116,5 +116,8 @@ void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, s
                       size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s);
 void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status, size_t G, int m, int want, uint32_t* bad, hipStream_t s);
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s);
+void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,
+                            uint32_t* bad, hipStream_t s);
+void launch_take_c0(int ew64, const uint64_t* coeffs, size_t G, int m, uint64_t* c0, hipStream_t s);
 
 }  // namespace hbmpc

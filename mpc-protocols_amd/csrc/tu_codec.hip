@@ -54,6 +54,17 @@ void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size
     if (ew64 == 4) hipLaunchKernelGGL(k_check_double<4>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
     else hipLaunchKernelGGL(k_check_double<1>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
 }
+void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,
+                            uint32_t* bad, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_double_c0<4>, grid, dim3(256), 0, s, c0t, degt, c02t, deg2t, G, t, bad);
+    else hipLaunchKernelGGL(k_check_double_c0<1>, grid, dim3(256), 0, s, c0t, degt, c02t, deg2t, G, t, bad);
+}
+void launch_take_c0(int ew64, const uint64_t* coeffs, size_t G, int m, uint64_t* c0, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_take_c0<4>, grid, dim3(256), 0, s, coeffs, G, m, c0);
+    else hipLaunchKernelGGL(k_take_c0<1>, grid, dim3(256), 0, s, coeffs, G, m, c0);
+}
 // the matrix-core byte-digit table expanded on the device from rows x m canonical coefficients (kernels_tables.hpp);
 // partial: rows * m scratch elements
 void launch_mfma_table(const uint64_t* coeff, int m, int rows, const uint64_t e[4], uint32_t bmag, uint8_t* table, uint64_t* partial,

@@ -201,3 +201,68 @@ def test_producers_at_a_size_that_takes_the_large_batch_kernels():
         rd.close()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,t,K", [(16, 5, 3000), (7, 2, 9000), (13, 4, 4001)])
+def test_fused_producer_steps_write_the_same_bytes(n, t, K):
+    """The mixing step that writes the parties' lists itself (k_mfma_bfly<.., LISTS>) and the verifier interpolation that keeps
+    only c0 and the degree (hbmpc_dev_batch_interpolate_c0) against the separate passes (hbmpc_set_producer_fusion(ctx, 0):
+    every row into y, hbmpc_dev_transpose, full coefficient rows + hbmpc_dev_check_double_share): whole outputs, verdicts and
+    the first failing column, for RanSha, RanDouSha and the two-slice split of Preprocessing (a | b of TripleGen)."""
+    from oracle import cref as O
+    import ctypes as C
+    pkg = load_package()
+    eng = pkg.Engine(0)
+    try:
+        co = O.fill_random(11 + n, n * K * (t + 1)).reshape(n, K, t + 1, 4)
+        ct = O.fill_random(12 + n, n * K * (t + 1)).reshape(n, K, t + 1, 4)
+        c2t = O.fill_random(13 + n, n * K * (2 * t + 1)).reshape(n, K, 2 * t + 1, 4)
+        c2t[:, :, 0] = ct[:, :, 0]
+        c2t[2, K // 3, 0, 1] ^= np.uint64(4)          # one column fails the equal-secret test
+        ct[1, K // 2, t] = 0                           # ... one has a degree-t polynomial of lower degree (dealer 1's; the column sums still have degree t)
+        res = {}
+        for fused in (1, 0):
+            assert eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(fused)) == 0
+            rs = pkg.pipelines.RanSha(eng, n, t, K)
+            rs.upload(co)
+            rs.run(check=True)
+            out = rs.download().copy()
+            rs.deal()
+            off = ((1 * n + 2) * K + K - 5) * 32
+            cur = eng._new((1,))
+            eng.d2h(cur, rs.S + off)
+            eng.sync()
+            cur[0, 0] ^= np.uint64(1)
+            eng.h2d(rs.S + off, cur)
+            rs.finish(check=False)
+            res[fused] = [out, rs._bad()]
+            rs.close()
+            rd = pkg.pipelines.RanDouSha(eng, n, t, K)
+            rd.upload(ct, c2t)
+            rd.run(check=False)
+            a, b = rd.download()
+            res[fused] += [a.copy(), b.copy(), rd._bad()]
+            rd.close()
+        assert np.array_equal(res[1][0], res[0][0]) and res[1][1] == res[0][1] and res[1][1][0] >= 1 and res[1][1][1] == K - 5
+        assert np.array_equal(res[1][2], res[0][2]) and np.array_equal(res[1][3], res[0][3]) and res[1][4] == res[0][4]
+        assert res[1][4][0] == n - (t + 1) and res[1][4][1] == K // 3
+        # Preprocessing: the lists land in TripleGen's arrays through two slices (a = the first N of a party's list, b = the next N)
+        N = (2 * t + 1) * (n - 2 * t) * (t + 1) * 60
+        outs = {}
+        for fused in (1, 0):
+            assert eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(fused)) == 0
+            pre = pkg.pipelines.Preprocessing(eng, n, t, N)
+            pre.rs.upload(O.fill_random(21, n * pre.K_rs * (t + 1)).reshape(n, pre.K_rs, t + 1, 4))
+            dt = O.fill_random(22, n * pre.K_rd * (t + 1)).reshape(n, pre.K_rd, t + 1, 4)
+            d2t = O.fill_random(23, n * pre.K_rd * (2 * t + 1)).reshape(n, pre.K_rd, 2 * t + 1, 4)
+            d2t[:, :, 0] = dt[:, :, 0]
+            pre.rd.upload(dt, d2t)
+            pre.run(check=True)
+            outs[fused] = [pre.tg.download_named(nm, (n, N)).copy() for nm in ("a", "b", "rt", "r2t", "c")]
+            pre.close()
+        for x, y in zip(outs[1], outs[0]):
+            assert np.array_equal(x, y)
+    finally:
+        eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(1))
+        eng.close()
