@@ -46,7 +46,7 @@ def shard_range(total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prewarm_s=0.0, events=None):
+def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prewarm_s=0.0, events=None, manage_gc=True):
     """Untimed pre-warm by TIME (launch until prewarm_s seconds have passed: the chip's clocks and caches need a few
     hundred ms of load to settle, which a count of W short launches does not cover), then W untimed warmups, then
     EXACTLY K steps bracketed by barrier+sync.  `events` = (ev0, ev1, record) brackets the SAME K launches with two HIP
@@ -56,9 +56,13 @@ def timed_steps(step_fn, steps, warmup, sync_fn, barrier_fn, max_reduce_fn, prew
     # ~40 ms (seen as ONE 38 ms host call among thousands of 15 us ones, tools/time_needed_only.py), ten times the whole
     # K = 20 region.  Collect NOW -- before the pre-warm, so that the pause does not let the chip's clocks fall again
     # right before the timed launches -- and keep it off until they are done.
-    gc.collect()
-    gc_was_on = gc.isenabled()
-    gc.disable()
+    # (manage_gc = False: the caller -- one process driving several devices from threads -- holds the collector off for all of
+    # them; a thread that re-enabled it on finishing would switch it on under the others' timed regions)
+    gc_was_on = False
+    if manage_gc:
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
     t_pre = time.perf_counter()
     pre_steps = 0
     while prewarm_s > 0 and time.perf_counter() - t_pre < prewarm_s:
@@ -309,7 +313,7 @@ def bench_single_process(args, torch):
             ev = lambda: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), lambda e: e.record(ts))
             step()
             sync()
-            tm = timed_steps(step, args.steps, args.warmup, sync, bar.wait, lambda x: x, prewarm_s=args.prewarm_seconds, events=ev())
+            tm = timed_steps(step, args.steps, args.warmup, sync, bar.wait, lambda x: x, prewarm_s=args.prewarm_seconds, events=ev(), manage_gc=False)
             torch.manual_seed(0xC0FFEE02 + i)
             x = _rand_fr(torch, dev, B, d3 + 1)
             y = torch.empty((n3, B, 4), dtype=torch.int64, device=dev)
@@ -327,7 +331,7 @@ def bench_single_process(args, torch):
             rstep()
             sync()
             assert bool((co == x).all()) and int(st.max()) == 0, "decode(encode(x)) != x"
-            rtm = timed_steps(rstep, args.steps, args.warmup, sync, bar.wait, lambda x: x, prewarm_s=args.prewarm_seconds, events=ev())
+            rtm = timed_steps(rstep, args.steps, args.warmup, sync, bar.wait, lambda x: x, prewarm_s=args.prewarm_seconds, events=ev(), manage_gc=False)
             res[i] = (tm, rtm)
             keep[i] = (shares, ts)
         except BaseException as e:  # a thread that dies must not leave the others at the barrier
@@ -335,10 +339,15 @@ def bench_single_process(args, torch):
             bar.abort()
 
     th = [threading.Thread(target=worker, args=(i,)) for i in range(N)]
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()  # process-wide, for every thread's timed region
     for x in th:
         x.start()
     for x in th:
         x.join()
+    if gc_was_on:
+        gc.enable()
     if errs:
         raise SystemExit(f"--single-process: {errs}")
     secs = max(r[0]["secs"] for r in res)
@@ -380,10 +389,23 @@ def bench_single_process(args, torch):
         ms = g0.elapsed_time(g1)
         for i in range(N):
             assert torch.equal(full[:, i * B:(i + 1) * B].cpu(), keep[i][0].cpu()), f"gathered shard {i} differs"
+        # the same gather source by source (root + ONE peer per call): what each link delivers, next to whether the root reads that
+        # peer's memory directly (peer access over xGMI) or through a staged copy
+        per_source = []
+        for i in range(1, N):
+            for rep in range(2):
+                g0.record(ts0)
+                rc = pkg.Engine.gather_party_major([engines[0], engines[i]], 0, [ptrs[0], ptrs[i]], [0, B], [B, B], n, full.data_ptr(), B * N,
+                                                   sync_sources=True, stream=ts0.cuda_stream)
+                assert rc == 0, engines[0].last_error()
+                g1.record(ts0)
+                torch.cuda.synchronize()
+            per_source.append({"source_device": devno[i], "peer_access_direct": bool(peer[i]), "ms": g0.elapsed_time(g1),
+                               "GBps": n * B * 32 / g0.elapsed_time(g1) / 1e6})
         out["final_gather"] = {"ms": ms, "bytes_total": n * B * N * 32, "bytes_from_peers": n * B * (N - 1) * 32,
                                "GBps_from_peers": n * B * (N - 1) * 32 / ms / 1e6,
                                "copies": "one hipMemcpy2DAsync per shard on device 0's stream (hbmpc_dev_gather_party_major)",
-                               "peer_access_direct": peer}
+                               "peer_access_direct": peer, "per_source": per_source}
     if args.same_device:
         out["rehearsal"] = "every context on GPU 0: a check of the one-process control flow, not a measurement"
     return out
@@ -490,6 +512,13 @@ def main():
         out = bench_pipeline(ctx)
     if args.same_device:
         out["rehearsal"] = "all ranks on GPU 0 over gloo: a check of the N > 1 control flow, not a measurement"
+    if world > 1:
+        # how many ranks the collective layer really saw (an all-reduce of ones) and which backend carried it
+        ones = torch.ones(1, dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        out["ranks_seen"] = int(ones.item())
+        out["backend"] = dist.get_backend()
+        assert out["ranks_seen"] == world == out["n_gpus"], (out["ranks_seen"], world)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
@@ -545,6 +574,23 @@ def bench_metric(ctx):
     if rec:
         out["roofline"]["traffic"] = rec["hbm_bytes_per_launch"]
         out["roofline"]["traffic_source"] = rec["source"]
+    # context for `frac`, measured IN THIS RUN on the same buffers right behind the timed region (the chip is warm): the same
+    # loads and stores with no arithmetic at all (hbmpc_dev_traffic_ubench: x[B][d+1] -> y[n][B], every loaded word kept live)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        assert eng.dev_traffic_ubench(coeffs.data_ptr(), B, d + 1, shares.data_ptr(), n, stream) == 0, eng.last_error()
+    e0.record()
+    for _ in range(20):
+        eng.dev_traffic_ubench(coeffs.data_ptr(), B, d + 1, shares.data_ptr(), n, stream)
+    e1.record()
+    torch.cuda.synchronize()
+    no_arith_ms = e0.elapsed_time(e1) / 20
+    out["roofline"]["same_traffic_no_arithmetic_ms"] = no_arith_ms
+    out["roofline"]["same_traffic_no_arithmetic_GBps"] = algo_bytes / (no_arith_ms * 1e-3) / 1e9
+    out["roofline"]["same_traffic_no_arithmetic_source"] = ("hbmpc_dev_traffic_ubench on the benchmarked buffers, 20 launches behind the "
+                                                            "timed region of this run (HIP events)")
+    step()  # the shares the checks below look at
+    torch.cuda.synchronize()
 
     final_gather = None
     if world > 1 and not args.no_final_gather:
@@ -553,14 +599,14 @@ def bench_metric(ctx):
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         dist.barrier()
         g0.record()
-        full = sharding.gather_party_major(shares, B * world)
+        full, spans = sharding.gather_shards(shares, B * world)  # [n][world][B]: a view of the one receive buffer
         g1.record()
         torch.cuda.synchronize()
-        lo_b = rank * B
-        assert torch.equal(full[:, lo_b:lo_b + B], shares)
+        assert tuple(full.shape[:3]) == (n, world, B) and spans[rank] == (rank * B, rank * B + B) and torch.equal(full[:, rank], shares)
         final_gather = {"ms": g0.elapsed_time(g1), "bytes_per_rank": n * B * 32,
                         "GBps_per_rank_received": n * B * 32 * (world - 1) / g0.elapsed_time(g1) / 1e6,
-                        "collective": "all_gather of the [n][B] shares of every rank (RCCL)"}
+                        "collective": "all_gather_into_tensor of the [n][B] shares of every rank into one [world][n][B] buffer "
+                                      "(RCCL), read party-major through a permuted view: no copy after the collective"}
         del full
     del coeffs, shares
 
@@ -618,11 +664,8 @@ def bench_metric(ctx):
             out["cpu_baseline_all_cores"] = cpu_baseline_threads(n, d, 1 << args.cpu_sample_log2)
             out["extra"] = extra_measurements(eng, torch, dev, stream)
             # context for `frac` (report against the vendor peak AND what the chip delivers): a plain
-            # device copy measured in this run, and -- a constant from an earlier measurement, not of this run -- the
-            # no-arithmetic kernel with exactly this kernel's traffic (27 % reads / 73 % writes)
+            # device copy measured in this run (the no-arithmetic form of this kernel's own traffic is measured above)
             out["roofline"]["peak_measured_copy_GBps"] = out["extra"]["device_copy_GBps"]
-            out["roofline"]["same_traffic_no_arithmetic_GBps_r01_constant"] = 4900.0
-            out["roofline"]["same_traffic_no_arithmetic_source"] = "tools/ubench_store.hip, profiles/r01_store_pattern_ubench.txt (not measured in this run)"
     return out
 
 

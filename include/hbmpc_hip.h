@@ -142,6 +142,9 @@ ShareErrorCode hbmpc_dev_gather_party_major(hbmpc_ctx* const* ctxs, size_t n_sha
  * call enables): the gather is then one strided copy per shard; 0 when the runtime has to stage the rows through the
  * host.  (The reference has no counterpart: its parties exchange bytes through the Network trait.) */
 ShareErrorCode hbmpc_dev_peer_access(hbmpc_ctx* root, hbmpc_ctx* source, int* direct_out);
+/* on != 0: the root context's gathers take the per-row peer copies (the branch of device pairs without peer access) even where
+ * the one 2-D copy per shard applies -- an A/B aid and the way to exercise that branch on a box with one device; same bytes. */
+ShareErrorCode hbmpc_set_gather_row_copies(hbmpc_ctx* root, int on);
 
 /* ---- HIP graphs (for hosts without their own HIP binding) ----------------------------------------
  * The reference's regime is many small protocol steps (a few hundred elements per message); a device-resident
@@ -741,6 +744,10 @@ ShareErrorCode hbmpc_set_second_chance(hbmpc_ctx* ctx, int on);
  * Runs `iters` dependent modmuls in each of `threads` lanes, writes one U256 per lane to out_dev
  * (so nothing is optimised away) and returns nothing else; time it with events on `stream`. */
 ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev, size_t threads, uint32_t iters, void* stream);
+/* measurement aid: the memory traffic of an encode with no arithmetic -- reads x[G][m] chunk-major, writes y[n][G] party-major in
+ * the access shapes of the matrix-core encode (every loaded word reaches every stored value) -- so that a bench line can state
+ * what the memory system delivers for exactly its kernel's loads and stores, measured in the same run. */
+ShareErrorCode hbmpc_dev_traffic_ubench(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t m, U256* y_dev, size_t n, void* stream);
 
 #ifdef __cplusplus
 }

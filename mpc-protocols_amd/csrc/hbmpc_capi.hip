@@ -62,6 +62,7 @@ struct hbmpc_ctx {
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
     int lazy_fallback_tables = 1;                  // a new sender set's OEC / Gao and second-chance tables are built when a chunk needs them: 1 = host-pointer calls, 2 = all
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
+    bool gather_row_copies = false;                // hbmpc_dev_gather_party_major: take the per-row peer copies even where the 2-D copy applies (A/B aid)
     bool list_rows_in_kernel = true;               // the producers' mixing step writes the parties' lists itself (k_mfma_bfly<.., LISTS>)
     bool mfma_bfly = true;                         // large encodes take the domain points in pairs (kernels_mfma_bfly.hpp)
     bool mfma_team = true;                         // batches with fewer tiles than waves: a workgroup per tile (kernels_mfma_team.hpp)
@@ -110,6 +111,18 @@ static size_t ebytes(const hbmpc_ctx* ctx) { return impl_ebytes(ctx->impl); }
 // Looks the table up or builds it, all under ctx->mu.  `aux` (optional): in = what the builder computed alongside the
 // words (read after build() returns), out = what is stored with the table -- a table and its offsets are published
 // together, so a second thread that finds the table cached also finds its layout.
+// frees a fresh device block unless it was published (the HIP_TRY early returns between hipMalloc and the cache entry)
+struct DevBlockGuard {
+    uint32_t* p = nullptr;
+    ~DevBlockGuard() {
+        if (p) (void)hipFree(p);
+    }
+    uint32_t* release() {
+        uint32_t* q = p;
+        p = nullptr;
+        return q;
+    }
+};
 template <class Build>
 static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build build, const uint32_t** out,
                                 std::array<size_t, 5>* aux = nullptr) {
@@ -142,13 +155,13 @@ static ShareErrorCode get_table(hbmpc_ctx* ctx, const std::string& key, Build bu
     }
     std::vector<uint32_t> host = build();
     if (host.empty()) host.push_back(0);
-    uint32_t* dev = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dev, host.size() * 4));
-    HIP_TRY(ctx, hipMemcpy(dev, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    DevBlockGuard blk;
+    HIP_TRY(ctx, hipMalloc(&blk.p, host.size() * 4));
+    HIP_TRY(ctx, hipMemcpy(blk.p, host.data(), host.size() * 4, hipMemcpyHostToDevice));
     hbmpc_ctx::Tab& tab = ctx->tables[key];
-    tab.p = dev;
+    tab.p = blk.release();
     if (aux) tab.aux = *aux;
-    *out = dev;
+    *out = tab.p;
     return ShareSuccess;
 }
 // A table whose bulk is EXPANDED ON THE DEVICE from a small host-built seed (the matrix-core byte-digit table: a few KB of
@@ -180,16 +193,18 @@ static ShareErrorCode get_table_expanded(hbmpc_ctx* ctx, const std::string& key,
             t = ctx->tables.erase(t);
         }
     }
+    // (ctx->mu is held across the build and the drain of the context's own stream: a second thread that wants the SAME new table
+    // must find it finished, and builds are rare -- one per new sender set -- and short, two launches of a few microseconds)
     std::vector<uint32_t> seed = build_seed();
-    uint32_t* dev = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dev, (dev_words + seed.size() + 16) * 4));
-    HIP_TRY(ctx, hipMemcpyAsync(dev + dev_words, seed.data(), seed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    expand(dev, dev + dev_words, ctx->stream);
+    DevBlockGuard blk;
+    HIP_TRY(ctx, hipMalloc(&blk.p, (dev_words + seed.size() + 16) * 4));
+    HIP_TRY(ctx, hipMemcpyAsync(blk.p + dev_words, seed.data(), seed.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    expand(blk.p, blk.p + dev_words, ctx->stream);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // also keeps `seed` (pageable host memory) alive until the copy has run
     hbmpc_ctx::Tab& tab = ctx->tables[key];
-    tab.p = dev;
-    *out = dev;
+    tab.p = blk.release();
+    *out = tab.p;
     return ShareSuccess;
 }
 static bool table_cached(hbmpc_ctx* ctx, const std::string& key) {
@@ -343,6 +358,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
     }
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_set_gather_row_copies(hbmpc_ctx* ctx, int on) {  // either field
+    if (!ctx) return InvalidInput;
+    ctx->gather_row_copies = on != 0;
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_set_producer_fusion(hbmpc_ctx* ctx, int on) {  // either field
     if (!ctx) return InvalidInput;
     ctx->list_rows_in_kernel = on != 0;
@@ -458,7 +478,8 @@ extern "C" ShareErrorCode hbmpc_dev_gather_party_major(hbmpc_ctx* const* ctxs, s
     for (size_t r = 0; r < n_shards; ++r) {
         const int src_dev = ctxs[r]->device;
         bool direct = src_dev == rc_ctx->device;
-        if (!direct) {
+        if (rc_ctx->gather_row_copies) direct = false;  // A/B aid: the branch a pair of devices without peer access takes
+        else if (!direct) {
             int can = 0;
             HIP_TRY(rc_ctx, hipDeviceCanAccessPeer(&can, rc_ctx->device, src_dev));
             if (can) {
@@ -1466,6 +1487,15 @@ extern "C" ShareErrorCode hbmpc_dev_modmul_ubench(hbmpc_ctx* ctx, U256* out_dev,
     if (threads % 256) return fail(ctx, InvalidInput, "threads must be a multiple of 256");
     const ElemConsts cs = elem_consts(ctx->impl);
     BY_IMPL(k_modmul_ubench, WO(out_dev), iters, cs);
+    return ShareSuccess;
+}
+
+extern "C" ShareErrorCode hbmpc_dev_traffic_ubench(hbmpc_ctx* ctx, const U256* x_dev, size_t G, size_t m, U256* y_dev, size_t n, void* stream) {
+    REQ_FR(ctx);
+    if (!x_dev || !y_dev || G == 0 || m == 0 || n == 0 || m > 64 || n > 256) return fail(ctx, InvalidInput, "null buffer or shape out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_traffic_ubench, dim3((unsigned)ctx->n_cus), dim3(768), 0, pick(ctx, stream), (const uint4*)x_dev, G, (int)m, (uint4*)y_dev, (int)n);
+    HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
 

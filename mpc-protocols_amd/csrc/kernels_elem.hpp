@@ -272,4 +272,37 @@ __global__ __launch_bounds__(256) void k_modmul_ubench(uint32_t* __restrict__ ou
     F::store_lt2r(out + i * F::EW, F::mont(x, y));
 }
 
+// measurement aid: the memory traffic of an encode with NO arithmetic -- x[G][m] chunk-major in, y[n][G] party-major out, in the
+// access shapes of kernels_mfma_bfly.hpp (a lane pair per chunk: 16-byte loads at a stride of 32 m bytes, 1 KiB contiguous per wave
+// store; a wave walks 32-chunk tiles in a grid-stride loop, the next tile's loads issued before the current tile's stores).  Every
+// loaded dword reaches every stored value, so nothing is dropped as dead.
+__global__ __launch_bounds__(768) void k_traffic_ubench(const uint4* __restrict__ x, size_t G, int m, uint4* __restrict__ y, int n) {
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const size_t ntiles = (G + 31) / 32, tstep = (size_t)gridDim.x * (blockDim.x >> 6);
+    size_t t = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    auto load = [&](size_t tile) {
+        const size_t gi = tile * 32 + c, g = gi < G ? gi : G - 1;
+        uint4 acc = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < m; ++i) {
+            const uint4 v = x[(g * m + i) * 2 + h];
+            acc.x ^= v.x, acc.y += v.y, acc.z ^= v.z, acc.w += v.w;
+        }
+        return acc;
+    };
+    if (t >= ntiles) return;
+    uint4 cur = load(t);
+    for (; t < ntiles; t += tstep) {
+        const uint4 nxt = load(t + tstep < ntiles ? t + tstep : t);
+        const size_t g = t * 32 + c;
+        if (g < G) {
+            for (int j = 0; j < n; ++j) {
+                uint4 v = cur;
+                v.x += (uint32_t)j;
+                y[((size_t)j * G + g) * 2 + h] = v;
+            }
+        }
+        cur = nxt;
+    }
+}
+
 }  // namespace hbmpc

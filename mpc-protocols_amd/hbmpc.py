@@ -521,6 +521,11 @@ class Engine:
         return self.L.hbmpc_dev_validate_canonical(self.ctx, C.c_void_p(a_d), C.c_size_t(N), C.c_void_p(status_d),
                                                    C.c_void_p(stream))
 
+    def dev_traffic_ubench(self, x_d, G, m, y_d, n, stream=0):
+        """x[G][m] -> y[n][G] with no arithmetic: what the memory system delivers for an encode's loads and stores"""
+        return self.L.hbmpc_dev_traffic_ubench(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(m), C.c_void_p(y_d), C.c_size_t(n),
+                                               C.c_void_p(stream))
+
     def dev_modmul_ubench(self, out_d, threads, iters, stream=0):
         return self.L.hbmpc_dev_modmul_ubench(self.ctx, C.c_void_p(out_d), C.c_size_t(threads), C.c_uint32(iters),
                                               C.c_void_p(stream))

@@ -7,6 +7,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -46,3 +48,18 @@ def test_spawns_the_ranks_and_returns_their_exit_code():
     assert out.returncode != 0
     assert out.stderr.count("needs an MI355X") >= 1, out.stderr[-2000:]
     assert out.stdout.strip() == ""  # no bench record
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["cfg2+cfg3", "cfg4"])
+def test_two_ranks_on_one_gpu_report_what_the_collective_layer_saw(workload):
+    """The N > 1 path end to end on the one GPU of the test box: `bench.py --gpus 2 --same-device --dist-backend gloo` starts its
+    own launcher, both ranks run their shard on GPU 0, barrier + max-reduce timing, the final gather, and rank 0's line says
+    how many ranks the collective layer really saw (an all-reduce of ones) and which backend carried it."""
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+                          "--log2-batch", "14", "--no-extra", "--prewarm-seconds", "0.05", "--workload", workload],
+                         capture_output=True, text=True, env=_env(), timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+    assert "rehearsal" in rec and rec["final_gather"]["ms"] > 0

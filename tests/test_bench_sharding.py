@@ -80,7 +80,20 @@ def _gather_worker(rank, world, port, q):
     assert rc == 0
     got = sharding.gather_party_major(torch.from_numpy(mine.view(np.int64)), total)
     rc, want = cref.compute_shares(coeffs, n, d)
-    q.put((rank, bool(np.array_equal(got.numpy().view(np.uint64), want)), tuple(got.shape)))
+    ok = bool(np.array_equal(got.numpy().view(np.uint64), want))
+    # equal shards (100 over 2 ranks): the permuted view of the ONE receive buffer, no copy -- and the dense form made from it
+    total2 = 100
+    lo2, hi2 = sharding.shard_range(total2, rank, world)
+    rc, mine2 = cref.compute_shares(coeffs[lo2:hi2], n, d)
+    view, spans = sharding.gather_shards(torch.from_numpy(mine2.view(np.int64)), total2)
+    rc, want2 = cref.compute_shares(coeffs[:total2], n, d)
+    ok = ok and tuple(view.shape) == (n, world, 50, 4) and spans == [(0, 50), (50, 100)] and not view.is_contiguous()
+    ok = ok and view._base is not None and view._base.numel() == world * n * 50 * 4        # a view of the one receive buffer
+    for r in range(world):
+        ok = ok and bool(np.array_equal(view[:, r].numpy().view(np.uint64), want2[:, spans[r][0]:spans[r][1]]))
+    dense = sharding.gather_party_major(torch.from_numpy(mine2.view(np.int64)), total2)
+    ok = ok and dense.is_contiguous() and bool(np.array_equal(dense.numpy().view(np.uint64), want2))
+    q.put((rank, ok, tuple(got.shape)))
     dist.destroy_process_group()
 
 

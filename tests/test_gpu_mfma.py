@@ -186,6 +186,19 @@ def test_gather_party_major_two_contexts():
         e0.sync()
         got = out.cpu().numpy().view(np.uint64)
         assert np.array_equal(got[:, :B], want) and (got[:, B:] == np.uint64(0xFFFFFFFFFFFFFFFF)).all()
+        # the branch of device pairs WITHOUT peer access (one peer copy per row), forced on this one-device box: same bytes,
+        # output pitch (B + 5) and source pitch (lo + 3) both different from the copied width
+        import ctypes as C
+        out.fill_(-1)
+        torch.cuda.synchronize()
+        assert e0.L.hbmpc_set_gather_row_copies(e0.ctx, C.c_int(1)) == 0
+        rc = pkg.Engine.gather_party_major([e0, e1], 0, [s0.data_ptr(), s1.data_ptr()], [lo, B - lo], [lo + 3, B - lo], n,
+                                           out.data_ptr(), B + 5)
+        assert rc == 0, e0.last_error()
+        e0.sync()
+        got2 = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got2, got)
+        assert e0.L.hbmpc_set_gather_row_copies(e0.ctx, C.c_int(0)) == 0
         assert e0.peer_access(e1) is True  # same device: direct (on a multi-GPU node: peer access over xGMI, enabled by the call)
         # argument checks: stride below count, field mismatch
         assert pkg.Engine.gather_party_major([e0, e1], 0, [s0.data_ptr(), s1.data_ptr()], [lo, B - lo], [lo - 1, B - lo], n,
