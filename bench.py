@@ -751,16 +751,15 @@ def bench_pipeline(ctx):
         dom_name = "k_mfma_bfly<11,8,8,TRIPLE,2>"     # the local products inside the matrix-core encode (kernels_mfma_bfly.hpp)
         step_bytes = dom_bytes + (n * n * G + n * G) * 32 + (n * G + N) * 32 + n * N * 64 + N * 32
         tkey = f"triple_encode_parties_n{n}_t{t}_N{N}"
-        limiter = ("vector issue at the sustained clock as much as HBM: 11 lazy products + Montgomery reductions per chunk of 11 triples and 16 "
-                   "carry / reduction epilogues; the same launch with loads and stores only takes 1.92 ms (5.0 TB/s), "
-                   "profiles/r03_mfma_bfly_triple.txt")
+        limiter = ("HBM on a 67 % read / 33 % write stream of 32-byte elements at a 352-byte stride: the same launch with loads and stores only "
+                   "(every load kept live) takes 2.14 ms against 2.17 - 2.25 ms, profiles/r04_ablations_all_loads_live.txt")
     else:
         dom = lambda: eng.dev_fpmul_middle(fp.tc, fp.x, fp.y, fp.dop, fp.eop, fp.rbits, fp.rint, k, f, N, n, fp.z, fp.rdash, fp.osh, stream)
         dom_bytes = n * N * 32 * (7 + f) + 2 * N * 32  # c, x, y, r_int, f bit shares read, z, r', open share written per party; d, e once
         dom_name = "k_fpmul_middle<U29>"
         step_bytes = dom_bytes + n * N * 32 * 6 + (2 * t + 1) * 3 * N * 32 + 3 * N * 32 + n * N * 32 * 3 + N * 32
         tkey = f"fpmul_middle_n{n}_t{t}_N{N}_f{f}"
-        limiter = "HBM (element-wise, 5 - 6 TB/s: profiles/r02_cfg5_kernel_stats.csv)"
+        limiter = "HBM (element-wise, 5 - 6 TB/s: profiles/r04_cfg5_kernel_stats.csv)"
     for _ in range(3):
         dom()
     torch.cuda.synchronize()
