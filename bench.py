@@ -1162,9 +1162,20 @@ def pipeline_measurements(eng, torch, dev, stream, ev_time):
     ms_eager = ev_time(lambda: fp.run(check=False), reps=20, warm=2)
     fp.capture()
     ms_graph = ev_time(fp.replay, reps=20, warm=2)
-    res["cfg5_fpmul_small_batch"] = {"elements": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
-                                     "fpmuls_per_s_hip_graph": Ns / ms_graph * 1e3}
     fp.close()
+    # the same as the five separate launches (one per step) instead of one
+    import ctypes as _C
+    eng.L.hbmpc_set_fused_fpmul(eng.ctx, _C.c_size_t(0))
+    fp = setup_fpmul(eng, torch, dev, stream, n, t, Ns, k, m)
+    fp.run(check=True)
+    ms_eager5 = ev_time(lambda: fp.run(check=False), reps=20, warm=2)
+    fp.capture()
+    ms_graph5 = ev_time(fp.replay, reps=20, warm=2)
+    fp.close()
+    eng.L.hbmpc_set_fused_fpmul(eng.ctx, _C.c_size_t(2048))
+    res["cfg5_fpmul_small_batch"] = {"elements": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
+                                     "fpmuls_per_s_hip_graph": Ns / ms_graph * 1e3, "launches": 1,
+                                     "five_launches": {"ms_eager": ms_eager5, "ms_hip_graph": ms_graph5}}
     # in between: 8192 elements -- each of the three opens is ONE matrix-core launch (workgroup per tile) once its sender
     # set has been seen twice
     Nm = 8192

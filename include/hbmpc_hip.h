@@ -426,6 +426,25 @@ ShareErrorCode hbmpc_dev_fpmul_middle(hbmpc_ctx* ctx, const U256* c, const U256*
  * de_sh_out[party][0][N] = a - x, [party][1][N] = b - y.  One robust interpolation over 2 N values per sender
  * (hbmpc_dev_batch_recover_p0 with G = 2 N: the sender rows are the parties' rows of de_sh_out) then opens d and e
  * together -- one call instead of two; its output is d[N] followed by e[N]. */
+/* FPMulNode for every party of this device in one call (fpmul/fpmul.rs:61-110): Multiply's opened a - x and b - y
+ * (mul/multiplication.rs:417-426, :102-139), finalize_mul (:57-100), TruncPr's r' and opened share (truncpr.rs:277-297, :215) and
+ * its last step (:216-220).  Per-party arrays are [party][N] (r_bits [party][m][N]); sender_ids[S] are PARTY ids, degree and
+ * threshold t.  Outputs: de_out[2 N] the opened a - x then b - y; z, r', the share TruncPr opens; c_open_out[N] that share opened;
+ * d_out the parties' shares of the truncated product; status_out[2 N] as the two decodes leave it ([0, N) the second open's,
+ * [N, 2 N) the b - y half of the first); the two opens' summaries (either may be null).  A chunk that fails its verification
+ * opens to zero and is counted, and the steps after it run on that zero -- as a caller of the separate functions who does not
+ * look at the summary in between gets them.
+ * With exactly 2t + 1 senders (what the reference opens from: multiplication.rs:388, truncpr.rs:202) and at most
+ * hbmpc_set_fused_fpmul elements (default 2048) the call is ONE launch, a wave per element (csrc/kernels_fpmul_wave.hpp: at these
+ * sizes a multiplication is bound by launches and by a lone wave's chain of multiplications per step, not by bytes); otherwise it
+ * is the five launches hbmpc_dev_beaver_open_shares_paired, hbmpc_dev_batch_recover_p0 (2 N values per sender),
+ * hbmpc_dev_fpmul_middle, hbmpc_dev_batch_recover_p0, hbmpc_dev_truncpr_finalize_parties.  Every output buffer holds the same bytes
+ * either way; de_sh_ws [party][2][N] is the workspace of the five-launch form (contents unspecified afterwards). */
+ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* a, const U256* b, const U256* c,
+                                       const U256* x, const U256* y, const U256* r_bits, const U256* r_int, size_t k, size_t m, size_t N,
+                                       size_t n, size_t t, U256* de_sh_ws, U256* de_out, U256* z_out, U256* r_dash_out, U256* open_sh_out,
+                                       U256* c_open_out, U256* d_out, uint8_t* status_out, hbmpc_recover_summary* summary_first_dev,
+                                       hbmpc_recover_summary* summary_dev, void* stream);
 ShareErrorCode hbmpc_dev_beaver_open_shares_paired(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* x, const U256* y,
                                                    size_t N, size_t parties, U256* de_sh_out, void* stream);
 ShareErrorCode hbmpc_dev_truncpr_rdash(hbmpc_ctx* ctx, const U256* r_bits, size_t m, size_t N, U256* r_dash_out,
@@ -691,6 +710,9 @@ ShareErrorCode hbmpc_set_lazy_fallback_tables(hbmpc_ctx* ctx, int on);
 /* The producers' fused steps (the mixing step writes the parties' lists itself; the RanDouSha verifier's interpolation keeps
  * only c0 and the degree): on (default) / off = every row into y and separate copy / test passes (A/B aid; same bytes). */
 ShareErrorCode hbmpc_set_producer_fusion(hbmpc_ctx* ctx, int on);
+/* hbmpc_dev_fpmul_parties runs as one launch up to max_elements batch elements (default 2048; 0: always the five separate
+ * launches).  Same bytes either way (A/B aid). */
+ShareErrorCode hbmpc_set_fused_fpmul(hbmpc_ctx* ctx, size_t max_elements);
 /* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have
  * arrived (batch_recon.rs:371-389) -- has no OEC round: a chunk that fails the verification can only fail
  * (DecodingError, robust_interpolate.rs:625).  Such a call is ONE kernel launch: the decode kernel writes the failure

@@ -136,10 +136,10 @@ struct hbmpc_pipe {
         PL(hbmpc_memcpy_d2h(ctx, out, bad, 8, stream));
         PL(hbmpc_stream_sync(ctx, stream));
     }
-    void check_summary() {  // checked mode: a failed chunk ends the run where the reference's `?` would
+    void check_summary(const hbmpc_recover_summary* which = nullptr) {  // checked mode: a failed chunk ends the run where the reference's `?` would
         if (!checked) return;
         hbmpc_recover_summary s;
-        PL(hbmpc_memcpy_d2h(ctx, &s, summ, sizeof s, stream));
+        PL(hbmpc_memcpy_d2h(ctx, &s, which ? which : summ, sizeof s, stream));
         PL(hbmpc_stream_sync(ctx, stream));
         if (s.n_failed != 0) throw PipeError{(ShareErrorCode)s.first_error};
     }
@@ -194,6 +194,7 @@ struct FpMul : hbmpc_pipe {
     size_t n, t, N, k, m;
     U256 *x, *y, *ta, *tb, *tc, *rint, *z, *rdash, *osh, *out, *desh, *rbits, *dop, *eop, *cop;
     uint8_t* status;
+    hbmpc_recover_summary* summ_first;  // the first open's (summ: the second's)
     std::vector<size_t> ids;
     FpMul(hbmpc_ctx* cx, size_t n_, size_t t_, size_t N_, size_t k_, size_t m_, size_t open_senders, void* s)
         : hbmpc_pipe(cx, s), n(n_), t(t_), N(N_), k(k_), m(m_) {
@@ -211,21 +212,16 @@ struct FpMul : hbmpc_pipe {
         cop = reinterpret_cast<U256*>(take("cop", N));
         status = take_bytes("status", 2 * N, 2 * N);
         summ = reinterpret_cast<hbmpc_recover_summary*>(take_bytes("summary", 64, 16));
+        summ_first = reinterpret_cast<hbmpc_recover_summary*>(take_bytes("summary_first", 64, 16));
         for (size_t i = 0; i < open_senders; ++i) ids.push_back(i);
     }
-    void open(const U256* shares, U256* dst, size_t values) {
-        PL(hbmpc_dev_batch_recover_p0(ctx, ids.data(), ids.size(), shares, values, n, t, t, dst, status, summ, stream));
-        check_summary();
-    }
     void run() override {
-        // one launch per step for all parties (the [party][N] arrays are contiguous; opened values are broadcast)
-        PL(hbmpc_dev_beaver_open_shares_paired(ctx, ta, tb, x, y, N, n, desh, stream));  // multiplication.rs:417-426
-        // reconstruct_rbc: per-element recover_secret of a - x and of b - y (:102-139) -- ONE call over the 2 N values of a sender row
-        open(desh, dop, 2 * N);
-        // finalize_mul (:57-100), r' (truncpr.rs:277-283) and the share TruncPr opens (:294-297): one launch
-        PL(hbmpc_dev_fpmul_middle(ctx, tc, x, y, dop, eop, rbits, rint, k, m, N, n, z, rdash, osh, stream));
-        open(osh, cop, N);  // truncpr.rs:215
-        PL(hbmpc_dev_truncpr_finalize_parties(ctx, z, rdash, cop, m, N, n, out, stream));  // :216-220
+        // all parties at once (the [party][N] arrays are contiguous; opened values are broadcast): one launch for a small batch,
+        // one per step otherwise (hbmpc_dev_fpmul_parties).  Checked mode looks at the two opens' summaries afterwards, in order.
+        PL(hbmpc_dev_fpmul_parties(ctx, ids.data(), ids.size(), ta, tb, tc, x, y, rbits, rint, k, m, N, n, t, desh, dop, z, rdash, osh, cop, out,
+                                   status, summ_first, summ, stream));
+        check_summary(summ_first);
+        check_summary(summ);
     }
 };
 

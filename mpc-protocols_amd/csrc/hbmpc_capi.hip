@@ -18,6 +18,7 @@
 #include "../../include/hbmpc_hip.h"
 #include "fr_gold.hpp"
 #include "kernels_elem.hpp"
+#include "kernels_fpmul_wave.hpp"
 #include "launchers.hpp"
 #include "tables.hpp"
 #include "tables_mfma.hpp"
@@ -62,6 +63,7 @@ struct hbmpc_ctx {
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
     int lazy_fallback_tables = 1;                  // a new sender set's OEC / Gao and second-chance tables are built when a chunk needs them: 1 = host-pointer calls, 2 = all
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
+    size_t fused_fpmul_max = 2048;                 // hbmpc_dev_fpmul_parties: one launch (a wave per element) up to this many elements (0: never)
     bool gather_row_copies = false;                // hbmpc_dev_gather_party_major: take the per-row peer copies even where the 2-D copy applies (A/B aid)
     bool list_rows_in_kernel = true;               // the producers' mixing step writes the parties' lists itself (k_mfma_bfly<.., LISTS>)
     bool mfma_bfly = true;                         // large encodes take the domain points in pairs (kernels_mfma_bfly.hpp)
@@ -84,6 +86,7 @@ static thread_local std::string g_err;
 // > 0 while the calling thread is between hbmpc_graph_begin_capture and _end_capture (capture mode is thread-local):
 // tables and scratch it looks up are then pinned for the graph's lifetime, and nothing may be allocated
 static thread_local int g_capturing = 0;
+// internal: batch_recover_dev was asked to form the senders' values at load time and the call cannot take that form
 
 #define HIP_TRY(ctx, call)                                                                              \
     do {                                                                                                \
@@ -358,6 +361,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
     }
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_set_fused_fpmul(hbmpc_ctx* ctx, size_t max_elements) {
+    if (!ctx) return InvalidInput;
+    ctx->fused_fpmul_max = max_elements;
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_set_gather_row_copies(hbmpc_ctx* ctx, int on) {  // either field
     if (!ctx) return InvalidInput;
     ctx->gather_row_copies = on != 0;
@@ -546,6 +554,8 @@ extern "C" ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream) {
 struct hbmpc_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipStream_t captured_on = nullptr;  // the stream whose scratch (decode counters) the recorded kernels point into
+    void* scratch = nullptr;
 };
 extern "C" ShareErrorCode hbmpc_graph_begin_capture(hbmpc_ctx* ctx, void* stream) {
     if (!ctx) return InvalidInput;
@@ -568,12 +578,30 @@ extern "C" ShareErrorCode hbmpc_graph_end_capture(hbmpc_ctx* ctx, void* stream, 
         hbmpc_graph_destroy(g);
         return HBMPC_NO_DEVICE;
     }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->scratch.find((hipStream_t)stream);
+        g->captured_on = (hipStream_t)stream;
+        g->scratch = it != ctx->scratch.end() ? it->second.p : nullptr;
+    }
     *graph_out = g;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_graph_launch(hbmpc_ctx* ctx, hbmpc_graph* graph, void* stream) {
     if (!ctx || !graph || !graph->exec) return InvalidInput;
-    HIP_TRY(ctx, hipGraphLaunch(graph->exec, pick(ctx, stream)));
+    hipStream_t s = pick(ctx, stream);
+    {
+        // the recorded decodes expect their counters at zero and carry no clear of their own (batch_recover_dev): a call that
+        // failed between its launches since the capture is the one case in which they are not
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->scratch.find(graph->captured_on);
+        if (graph->scratch && it != ctx->scratch.end() && it->second.p == graph->scratch && it->second.dirty) {
+            HIP_TRY(ctx, hipSetDevice(ctx->device));
+            HIP_TRY(ctx, hipMemsetAsync(graph->scratch, 0, 128, s));
+            it->second.dirty = false;
+        }
+    }
+    HIP_TRY(ctx, hipGraphLaunch(graph->exec, s));
     return ShareSuccess;
 }
 extern "C" void hbmpc_graph_destroy(hbmpc_graph* graph) {
@@ -1856,3 +1884,93 @@ extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const 
 }
 
 #include "capi_recover.inc"
+
+// ---- FPMulNode for all parties on this device (fpmul/fpmul.rs:61-110) ----------------------------------------------------------
+// The table of k_fpmul_wave: the verify rows and the P(0) row of the decode's table, and the P(0) row scaled by R (its
+// dot product is the opened value in Montgomery form: what finalize_mul multiplies the shares by)
+static ShareErrorCode fpmul_wave_table(hbmpc_ctx* ctx, const SortedSenders& ss, size_t n, size_t t, const uint32_t** out) {
+    const int impl = ctx->impl;
+    const std::shared_ptr<const DomainInv<HFr>> dom = domain_inv<HFr>(ctx, n);
+    return get_table(ctx, ids_key("fpw", ss.ids, 2 * t + 1, n, t, t, impl), [&] {
+        const auto rows = recover_coeff_rows<HFr>(*dom, ss.ids, t, t);  // t verify rows, then the coefficient rows
+        const HFr R = rdev_value(impl);
+        std::vector<uint32_t> w;
+        for (size_t r = 0; r <= t; ++r)
+            for (size_t i = 0; i <= t; ++i) put_const(w, rows[r][i], impl);
+        for (size_t i = 0; i <= t; ++i) put_const(w, rows[t][i] * R, impl);
+        return w;
+    }, out);
+}
+extern "C" ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* a, const U256* b, const U256* c,
+                                                  const U256* x, const U256* y, const U256* r_bits, const U256* r_int, size_t k, size_t m, size_t N,
+                                                  size_t n, size_t t, U256* de_sh_ws, U256* de_out, U256* z_out, U256* r_dash_out,
+                                                  U256* open_sh_out, U256* c_open_out, U256* d_out, uint8_t* status_out,
+                                                  hbmpc_recover_summary* summary_first_dev, hbmpc_recover_summary* summary_dev, void* stream) {
+    REQ_FR(ctx);
+    if (k == 0) return fail(ctx, InvalidInput, "k must be >= 1 (2^(k-1))");
+    if (m > 4096) return fail(ctx, InvalidInput, "m beyond the supported range");
+    if (m % 8 != 0 && m / 8 >= 32) return fail(ctx, InvalidInput, "m: bytes[m/8] out of bounds in the reference");
+    if (!a || !b || !c || !x || !y || !r_int || (m && !r_bits) || !de_sh_ws || !de_out || !z_out || !r_dash_out || !open_sh_out || !c_open_out || !d_out)
+        return fail(ctx, InvalidInput, "null buffer");
+    if (N == 0 || n == 0 || n > 255) return fail(ctx, InvalidInput, "N, n out of range");
+    // Small batches: the whole multiplication is one launch, a wave per element (kernels_fpmul_wave.hpp).  Larger ones, calls
+    // with OEC rounds available (S > 2t + 1) and the other field implementations run the five separate launches below -- the
+    // same bytes in every output buffer.
+    if (N <= ctx->fused_fpmul_max && S == 2 * t + 1 && ctx->impl == IMPL_U29 && !ctx->force_generic && ctx->direct_fail && n <= 64 && t <= 30 &&
+        (4 + m) * n <= 4096) {
+        SortedSenders ss;
+        ShareErrorCode rc = validate_senders(ctx, sender_ids, S, N, n, t, t, &ss);
+        if (rc != ShareSuccess) return rc;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = pick(ctx, stream);
+        const int impl = ctx->impl;
+        FpmulWaveArgs fa;
+        memset(&fa, 0, sizeof fa);
+        fa.N = N, fa.parties = (int)n, fa.m = (int)m, fa.needed = (int)(2 * t + 1), fa.M = (int)(t + 1), fa.mask_bits = (int)(m > 256 ? 256 : m);
+        // the products of a table row are shared by up to four adjacent lanes (a DPP quad) while the rows still fit the wave
+        while (fa.lk1 < 2 && ((t + 2) << (fa.lk1 + 1)) <= 32 && ((size_t)2 << fa.lk1) <= t + 1) ++fa.lk1;
+        while (fa.lk3 < 2 && ((t + 1) << (fa.lk3 + 1)) <= 64 && ((size_t)2 << fa.lk3) <= t + 1) ++fa.lk3;
+        if (launch_fpmul_wave(fa, s, true)) {
+            rc = fpmul_wave_table(ctx, ss, n, t, &fa.tab);
+            if (rc != ShareSuccess) return rc;
+            rc = get_table(ctx, key("pow2", {m}, impl), [&] { return build_pow2(m, impl); }, &fa.pow2);
+            if (rc != ShareSuccess) return rc;
+            const HFr two = HFr::from_u64(2);
+            const HFr p2m = two.pow_u64(m), p2k = two.pow_u64(k - 1), inv = p2m.inv();
+            const ElemConsts cs = elem_consts(impl, &p2m, &p2k), ci = elem_consts(impl, &inv);
+            memcpy(fa.c0, cs.c0, sizeof fa.c0), memcpy(fa.c1, cs.c1, sizeof fa.c1), memcpy(fa.cinv, ci.c0, sizeof fa.cinv);
+            fa.ta = (const uint32_t*)a, fa.tb = (const uint32_t*)b, fa.tc = (const uint32_t*)c, fa.x = (const uint32_t*)x, fa.y = (const uint32_t*)y;
+            fa.r_bits = (const uint32_t*)r_bits, fa.r_int = (const uint32_t*)r_int;
+            fa.de_out = (uint32_t*)de_out, fa.z = (uint32_t*)z_out, fa.r_dash = (uint32_t*)r_dash_out, fa.open_sh = (uint32_t*)open_sh_out;
+            fa.out = (uint32_t*)d_out, fa.c_open = (uint32_t*)c_open_out, fa.status = status_out;
+            for (size_t i = 0; i < S; ++i) fa.rows.set(i, (unsigned)ss.ids[i]);  // the per-party arrays are indexed by party id
+            // the decodes' counters (see batch_recover_dev): zero between calls, cleared here only when that is not known
+            std::lock_guard<std::mutex> enqueue_lock(ctx->enqueue_mu);
+            void* scratch;
+            bool dirty = false;
+            rc = get_scratch(ctx, s, 2048, &scratch, &dirty);
+            if (rc != ShareSuccess) return rc;
+            fa.counters = (uint32_t*)scratch;
+            fa.summary_first = summary_first_dev ? (uint32_t*)summary_first_dev : fa.counters + 4;  // the scratch's local summary slot
+            fa.summary = summary_dev ? (uint32_t*)summary_dev : fa.counters + 4;
+            if (dirty) HIP_TRY(ctx, hipMemsetAsync(fa.counters, 0, 128, s));
+            set_scratch_dirty(ctx, s, true);
+            launch_fpmul_wave(fa, s, false);
+            HIP_TRY(ctx, hipGetLastError());
+            set_scratch_dirty(ctx, s, false);  // the kernel's last workgroup leaves the counters at zero
+            return ShareSuccess;
+        }
+    }
+    // the shares Multiply opens (multiplication.rs:417-426) and reconstruct_rbc's recover_secret of a - x and of b - y (:102-139):
+    // ONE interpolation over the 2 N values of a sender row
+    ShareErrorCode rc = hbmpc_dev_beaver_open_shares_paired(ctx, a, b, x, y, N, n, de_sh_ws, stream);
+    if (rc != ShareSuccess) return rc;
+    rc = hbmpc_dev_batch_recover_p0(ctx, sender_ids, S, de_sh_ws, 2 * N, n, t, t, de_out, status_out, summary_first_dev, stream);
+    if (rc != ShareSuccess) return rc;
+    // finalize_mul (:57-100), r' (truncpr.rs:277-283), the share TruncPr opens (:294-297), its open (truncpr.rs:215), the last step (:216-220)
+    rc = hbmpc_dev_fpmul_middle(ctx, c, x, y, de_out, de_out + N, r_bits, r_int, k, m, N, n, z_out, r_dash_out, open_sh_out, stream);
+    if (rc != ShareSuccess) return rc;
+    rc = hbmpc_dev_batch_recover_p0(ctx, sender_ids, S, open_sh_out, N, n, t, t, c_open_out, status_out, summary_dev, stream);
+    if (rc != ShareSuccess) return rc;
+    return hbmpc_dev_truncpr_finalize_parties(ctx, z_out, r_dash_out, c_open_out, m, N, n, d_out, stream);
+}

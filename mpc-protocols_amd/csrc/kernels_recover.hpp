@@ -520,8 +520,24 @@ struct WideArgs {
     RecoverArgs r;
     SecondArgs sc;  // used when fused != 0
     int fused;      // a chunk that fails the verification tries the second-chance candidates right here (same wave)
+    int tab_words;  // TAB instances: (needed - m + out_width) * m constants, r.vm and r.bc contiguous, staged in LDS
 };
-template <class F, bool P0_ONLY>
+// rows[i], i < 64, from the scalar side: a per-lane index into the argument struct compiles to a VECTOR load from the
+// argument segment -- a full memory round trip in front of the loads that depend on it; sixteen scalar words and a
+// select per word are not
+HB_DEV int row_of_lane(const RowsArg& rows, int i) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if ((i >> 2) == k) w = rows.w[k];
+    return (int)((w >> (8 * (i & 3))) & 0xffu);
+}
+// LDS of one workgroup (4 chunks): [4][needed] sender values | TAB: the verify and output rows' constants, staged once per
+// workgroup: both loads of a chunk -- table and sender values -- are in flight together and the m products of a row run
+// from LDS, instead of m dependent round trips for the constants and a fourth of the table traffic.  (At n = 16 a decode
+// of 1024 chunks takes 13 us either way: a lone wave per SIMD spends them in its ~570 16-cycle v_mad_u64_u32 and one
+// round trip; profiles/r04_small_batch_fpmul.txt.)
+template <class F, bool P0_ONLY, bool TAB = true>
 __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     using E = typename F::E;
     const RecoverArgs& a = wa.r;
@@ -533,16 +549,39 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     const size_t g = live ? g_raw : a.G - 1;
     const int M = a.m, nv = a.needed - M, ow = P0_ONLY ? 1 : M;
     uint32_t* ys = tile + (size_t)wave * a.needed * F::EW;
-    for (int i = lane; i < a.needed; i += 64) {
-        const uint32_t* src = a.evals + ((size_t)a.rows[i] * a.row_stride + g) * F::EW;
+    uint32_t* tab = tile + (size_t)4 * a.needed * F::EW;
+    // --- every global load first ---
+    const uint4* tsrc = reinterpret_cast<const uint4*>(a.vm);
+    const int tq = wa.tab_words >> 2;
+    uint4 t0 = make_uint4(0, 0, 0, 0);
+    if (TAB && (int)threadIdx.x < tq) t0 = tsrc[threadIdx.x];
+    {
+        uint32_t first[F::EW];
+        if (lane < a.needed) {
+            const uint32_t* src = a.evals + ((size_t)row_of_lane(a.rows, lane) * a.row_stride + g) * F::EW;
 #pragma unroll
-        for (int w = 0; w < F::EW; ++w) ys[i * F::EW + w] = src[w];
+            for (int w = 0; w < F::EW; ++w) first[w] = src[w];
+        }
+        if (TAB && (int)threadIdx.x < tq) reinterpret_cast<uint4*>(tab)[threadIdx.x] = t0;
+        if (lane < a.needed) {
+#pragma unroll
+            for (int w = 0; w < F::EW; ++w) ys[lane * F::EW + w] = first[w];
+        }
+        for (int i = lane + 64; i < a.needed; i += 64) {
+            const uint32_t* src = a.evals + ((size_t)a.rows[i] * a.row_stride + g) * F::EW;
+#pragma unroll
+            for (int w = 0; w < F::EW; ++w) ys[i * F::EW + w] = src[w];
+        }
+    }
+    if constexpr (TAB) {  // what one pass of the workgroup did not cover (tables beyond 4 KB), and the words past the last 16 bytes
+        for (int q = threadIdx.x + 256; q < tq; q += 256) reinterpret_cast<uint4*>(tab)[q] = tsrc[q];
+        for (int w = (tq << 2) + threadIdx.x; w < wa.tab_words; w += 256) tab[w] = a.vm[w];
     }
     __syncthreads();
     auto chunk = [&]() __attribute__((always_inline)) {
     if (!live) return;
     auto dot = [&](int r) -> E {  // r < nv: verify row r; else output row r - nv
-        const uint32_t* row = r < nv ? a.vm + (size_t)r * M * F::NL : a.bc + (size_t)(r - nv) * M * F::NL;
+        const uint32_t* row = TAB ? tab + (size_t)r * M * F::NL : r < nv ? a.vm + (size_t)r * M * F::NL : a.bc + (size_t)(r - nv) * M * F::NL;
         typename F::Acc acc;
         F::acc_zero(acc);
         int pending = 0;
@@ -557,15 +596,16 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
         F::acc_fold(acc);
         return F::acc_reduce(acc);
     };
+    auto expect = [&](int r) -> E { return F::load(ys + (size_t)(M + r) * F::EW); };  // the value verify row r is compared with
     // first sweep: rows lane, of verify and output rows alike (an output row's value waits in registers for the vote)
     bool bad = false, have = false;
     E kept = F::zero();
     if (lane < nv + ow) {
         kept = dot(lane);
-        if (lane < nv) bad = !F::eq_canon(F::canon_loose(kept), F::load(ys + (M + lane) * F::EW));
+        if (lane < nv) bad = !F::eq_canon(F::canon_loose(kept), expect(lane));
         else have = true;
     }
-    for (int r = lane + 64; r < nv; r += 64) bad = bad || !F::eq_canon(F::canon_loose(dot(r)), F::load(ys + (M + r) * F::EW));
+    for (int r = lane + 64; r < nv; r += 64) bad = bad || !F::eq_canon(F::canon_loose(dot(r)), expect(r));
     const bool ok = __ballot(bad) == 0;
     if (!ok && a.direct) {  // no OEC round: the failure is final (fail_chunk, one lane per output element)
         if (lane < ow) F::store_lt2r(a.out + (g * (size_t)ow + lane) * F::EW, F::zero());

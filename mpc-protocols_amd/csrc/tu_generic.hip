@@ -28,24 +28,42 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
         else hipLaunchKernelGGL((k_batch_recover_generic<Gold, false>), dim3(grid), dim3(256), 0, s, ra);
     }
 }
+// LDS of one workgroup of k_batch_recover_wide; *tab_words = 0 when the call's table cannot be staged (not contiguous, or
+// beyond what a launch may ask for without raising the function's limit)
+static size_t wide_lds(int impl, const RecoverArgs& ra, bool p0, int* tab_words) {
+    const size_t ew = impl == 2 ? 2 : 8, nl = impl == 0 ? 9 : impl == 1 ? 8 : 2;
+    const size_t nv = (size_t)(ra.needed - ra.m), ow = p0 ? 1 : (size_t)ra.m;
+    const size_t front = 4 * (size_t)ra.needed * ew * 4;
+    const size_t tw = (nv + ow) * (size_t)ra.m * nl;
+    const bool staged = ra.bc == ra.vm + nv * (size_t)ra.m * nl && ((uintptr_t)ra.vm & 15) == 0 && front + tw * 4 <= 64 * 1024;
+    *tab_words = staged ? (int)tw : 0;
+    return front + (staged ? tw * 4 : 0);
+}
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* sc, hipStream_t s) {
     const unsigned grid = (unsigned)((ra.G + 3) / 4);
-    const size_t ew = impl == 2 ? 2 : 8, lds = 4 * (size_t)ra.needed * ew * 4;  // one chunk's sender values per wave
     WideArgs wa;
     wa.r = ra;
     wa.fused = sc != nullptr;
     if (sc) wa.sc = *sc;
     else memset(&wa.sc, 0, sizeof wa.sc);
+    const size_t lds = wide_lds(impl, ra, p0, &wa.tab_words);
+    const bool tab = wa.tab_words != 0;
+#define HBMPC_WIDE(F, P0) \
+    do { \
+        if (tab) hipLaunchKernelGGL((k_batch_recover_wide<F, P0, true>), dim3(grid), dim3(256), lds, s, wa); \
+        else hipLaunchKernelGGL((k_batch_recover_wide<F, P0, false>), dim3(grid), dim3(256), lds, s, wa); \
+    } while (0)
     if (impl == 0) {
-        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<U29, true>), dim3(grid), dim3(256), lds, s, wa);
-        else hipLaunchKernelGGL((k_batch_recover_wide<U29, false>), dim3(grid), dim3(256), lds, s, wa);
+        if (p0) HBMPC_WIDE(U29, true);
+        else HBMPC_WIDE(U29, false);
     } else if (impl == 1) {
-        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Sat32, true>), dim3(grid), dim3(256), lds, s, wa);
-        else hipLaunchKernelGGL((k_batch_recover_wide<Sat32, false>), dim3(grid), dim3(256), lds, s, wa);
+        if (p0) HBMPC_WIDE(Sat32, true);
+        else HBMPC_WIDE(Sat32, false);
     } else {
-        if (p0) hipLaunchKernelGGL((k_batch_recover_wide<Gold, true>), dim3(grid), dim3(256), lds, s, wa);
-        else hipLaunchKernelGGL((k_batch_recover_wide<Gold, false>), dim3(grid), dim3(256), lds, s, wa);
+        if (p0) HBMPC_WIDE(Gold, true);
+        else HBMPC_WIDE(Gold, false);
     }
+#undef HBMPC_WIDE
 }
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s) {
     if (impl == 0) hipLaunchKernelGGL((k_second_chance<U29>), dim3(grid), dim3(256), 0, s, a);

@@ -93,6 +93,52 @@ def test_fpmul_pipeline(pkg_eng, n, t, N, k, m, senders):
         assert GU.eq(out[p], O.truncpr_finalize(z[p], rd, c_open, m)[1])
 
 
+@pytest.mark.parametrize("n,t,N,k,m", [(16, 5, 1000, 16, 4), (7, 2, 333, 32, 16), (4, 1, 2048, 16, 0), (16, 5, 3000, 16, 4)])
+def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
+    """FPMulNode for all parties in ONE launch (hbmpc_dev_fpmul_parties at a small batch: a wave per element,
+    csrc/kernels_fpmul_wave.hpp) against the five separate launches (hbmpc_set_fused_fpmul(ctx, 0)): every buffer a caller can
+    see -- the opened a - x | b - y, z, r', the shares TruncPr opens, the opened value, the output, the statuses -- byte for
+    byte, on sharings of random field elements (the steps are algebra, not range-limited) of which one is inconsistent (its
+    opens fail and count, the steps after them run on zero), eager and replayed as a graph."""
+    import ctypes as C
+    pkg, eng = pkg_eng
+    torch = pytest.importorskip("torch")
+    ts = torch.cuda.Stream(device=torch.device("cuda", 0))
+    names = ("dop", "eop", "z", "rdash", "osh", "cop", "out")
+    ins = [share_all(O.fill_random(900 + j, N), n, t, 910 + j) for j in range(6)]                    # x, y, a, b, c, r_int: sharings of random secrets
+    bits = np.stack([share_all(O.fill_random(990 + j, N), n, t, 950 + j) for j in range(m)], axis=1) if m else np.zeros((n, 0, N, 4), dtype=np.uint64)
+    ins[1][1, 5] = ins[1][2, 5]                                     # party 1's y share of element 5 is wrong: b - y fails, then the second open
+    ins[0][0, 5] = ins[0][2, 5]                                     # and party 0's x share: a - x fails too
+    res = {}
+    try:
+        for fused in (1 << 20, 0):
+            assert eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(fused)) == 0
+            fp = pkg.pipelines.FpMul(eng, n, t, N, k, m, stream=ts.cuda_stream)
+            fp.upload(ins[0], ins[1], ins[2], ins[3], ins[4], np.ascontiguousarray(bits), ins[5])
+            with pytest.raises(RuntimeError):
+                fp.run(check=True)
+            fp.run(check=False)
+            got = {}
+            for nm in names:
+                got[nm] = fp.download_named(nm, (N,) if nm in ("dop", "eop", "cop") else (n, N)).copy()
+            for nm, arr in (("status", np.zeros(2 * N, dtype=np.uint8)), ("summary", np.zeros(4, dtype=np.uint32)), ("summary_first", np.zeros(4, dtype=np.uint32))):
+                eng.d2h(arr, fp.buffer(nm)[0], ts.cuda_stream)
+                got[nm] = arr
+            eng.sync(ts.cuda_stream)
+            assert got["summary_first"].tolist() == [2, 2, 5, 8]      # a - x and b - y of element 5 (then d = e = 0: z = c, the second open is consistent)
+            assert got["summary"].tolist() == [0, 0, 0xffffffff, 0] and got["status"][N + 5] == 8 and not got["status"][:N].any()
+            fp.capture()
+            eng.h2d(fp.out, np.zeros((n, N, 4), dtype=np.uint64), ts.cuda_stream)
+            fp.replay()
+            assert GU.eq(fp.download("out"), got["out"])
+            res[fused] = got
+            fp.close()
+        for nm in names + ("status", "summary", "summary_first"):
+            assert np.array_equal(res[1 << 20][nm], res[0][nm]), nm
+    finally:
+        eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(2048))
+
+
 def test_fpmul_pipeline_as_hip_graph(pkg_eng):
     """The whole fpmul call sequence captured once into a HIP graph (hbmpc_graph_*) and replayed on refilled
     buffers gives exactly what the eager calls give."""
