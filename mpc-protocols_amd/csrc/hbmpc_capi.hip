@@ -1930,7 +1930,7 @@ extern "C" ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* 
         // the products of a table row are shared by up to four adjacent lanes (a DPP quad) while the rows still fit the wave
         while (fa.lk1 < 2 && ((t + 2) << (fa.lk1 + 1)) <= 32 && ((size_t)2 << fa.lk1) <= t + 1) ++fa.lk1;
         while (fa.lk3 < 2 && ((t + 1) << (fa.lk3 + 1)) <= 64 && ((size_t)2 << fa.lk3) <= t + 1) ++fa.lk3;
-        if (launch_fpmul_wave(fa, s, true)) {
+        if (launch_fpmul_wave(fa, ctx->device, s, true)) {
             rc = fpmul_wave_table(ctx, ss, n, t, &fa.tab);
             if (rc != ShareSuccess) return rc;
             rc = get_table(ctx, key("pow2", {m}, impl), [&] { return build_pow2(m, impl); }, &fa.pow2);
@@ -1955,7 +1955,7 @@ extern "C" ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* 
             fa.summary = summary_dev ? (uint32_t*)summary_dev : fa.counters + 4;
             if (dirty) HIP_TRY(ctx, hipMemsetAsync(fa.counters, 0, 128, s));
             set_scratch_dirty(ctx, s, true);
-            launch_fpmul_wave(fa, s, false);
+            launch_fpmul_wave(fa, ctx->device, s, false);
             HIP_TRY(ctx, hipGetLastError());
             set_scratch_dirty(ctx, s, false);  // the kernel's last workgroup leaves the counters at zero
             return ShareSuccess;

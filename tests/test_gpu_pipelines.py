@@ -93,7 +93,8 @@ def test_fpmul_pipeline(pkg_eng, n, t, N, k, m, senders):
         assert GU.eq(out[p], O.truncpr_finalize(z[p], rd, c_open, m)[1])
 
 
-@pytest.mark.parametrize("n,t,N,k,m", [(16, 5, 1000, 16, 4), (7, 2, 333, 32, 16), (4, 1, 2048, 16, 0), (16, 5, 3000, 16, 4)])
+@pytest.mark.parametrize("n,t,N,k,m", [(16, 5, 1000, 16, 4), (7, 2, 333, 32, 16), (4, 1, 2048, 16, 0), (16, 5, 3000, 16, 4), (31, 10, 257, 24, 8), (40, 13, 130, 16, 4),
+                                       (64, 21, 66, 16, 1)])
 def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
     """FPMulNode for all parties in ONE launch (hbmpc_dev_fpmul_parties at a small batch: a wave per element,
     csrc/kernels_fpmul_wave.hpp) against the five separate launches (hbmpc_set_fused_fpmul(ctx, 0)): every buffer a caller can
@@ -115,9 +116,12 @@ def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
             assert eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(fused)) == 0
             fp = pkg.pipelines.FpMul(eng, n, t, N, k, m, stream=ts.cuda_stream)
             fp.upload(ins[0], ins[1], ins[2], ins[3], ins[4], np.ascontiguousarray(bits), ins[5])
+            marker = O.fill_random(77, 2 * n * N).reshape(n, 2, N, 4)
+            fp.upload_named("desh", marker)                         # the five launches' workspace: the one launch leaves it alone
             with pytest.raises(RuntimeError):
                 fp.run(check=True)
             fp.run(check=False)
+            assert GU.eq(fp.download_named("desh", (n, 2, N)), marker) == (fused != 0), "which form ran"
             got = {}
             for nm in names:
                 got[nm] = fp.download_named(nm, (N,) if nm in ("dop", "eop", "cop") else (n, N)).copy()
