@@ -757,7 +757,9 @@ def bench_pipeline(ctx):
         dom = lambda: eng.dev_fpmul_middle(fp.tc, fp.x, fp.y, fp.dop, fp.eop, fp.rbits, fp.rint, k, f, N, n, fp.z, fp.rdash, fp.osh, stream)
         dom_bytes = n * N * 32 * (7 + f) + 2 * N * 32  # c, x, y, r_int, f bit shares read, z, r', open share written per party; d, e once
         dom_name = "k_fpmul_middle<U29>"
-        step_bytes = dom_bytes + n * N * 32 * 6 + (2 * t + 1) * 3 * N * 32 + 3 * N * 32 + n * N * 32 * 3 + N * 32
+        # the first open reads a, b, x, y of its 2t + 1 senders and forms their shares itself (four launches: hbmpc_dev_fpmul_parties);
+        # the second reads the 2t + 1 senders' open shares; d, e, c out; TruncPr's last step z, r' in, the output shares out
+        step_bytes = dom_bytes + (2 * t + 1) * 4 * N * 32 + (2 * t + 1) * N * 32 + 3 * N * 32 + n * N * 32 * 3 + N * 32
         tkey = f"fpmul_middle_n{n}_t{t}_N{N}_f{f}"
         limiter = "HBM (element-wise, 5 - 6 TB/s: profiles/r04_cfg5_kernel_stats.csv)"
     for _ in range(3):

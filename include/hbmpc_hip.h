@@ -438,8 +438,10 @@ ShareErrorCode hbmpc_dev_fpmul_middle(hbmpc_ctx* ctx, const U256* c, const U256*
  * hbmpc_set_fused_fpmul elements (default 2048) the call is ONE launch, a wave per element (csrc/kernels_fpmul_wave.hpp: at these
  * sizes a multiplication is bound by launches and by a lone wave's chain of multiplications per step, not by bytes); otherwise it
  * is the five launches hbmpc_dev_beaver_open_shares_paired, hbmpc_dev_batch_recover_p0 (2 N values per sender),
- * hbmpc_dev_fpmul_middle, hbmpc_dev_batch_recover_p0, hbmpc_dev_truncpr_finalize_parties.  Every output buffer holds the same bytes
- * either way; de_sh_ws [party][2][N] is the workspace of the five-launch form (contents unspecified afterwards). */
+ * hbmpc_dev_fpmul_middle, hbmpc_dev_batch_recover_p0, hbmpc_dev_truncpr_finalize_parties -- the first two as one from
+ * hbmpc_set_fpmul_pair_decode elements on (default 8192: the decode forms a - x and b - y of its 2t + 1 senders as it loads them).
+ * Every output buffer holds the same bytes in every form; de_sh_ws [party][2][N] is the workspace of the five-launch form (contents
+ * unspecified afterwards). */
 ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* a, const U256* b, const U256* c,
                                        const U256* x, const U256* y, const U256* r_bits, const U256* r_int, size_t k, size_t m, size_t N,
                                        size_t n, size_t t, U256* de_sh_ws, U256* de_out, U256* z_out, U256* r_dash_out, U256* open_sh_out,
@@ -713,6 +715,10 @@ ShareErrorCode hbmpc_set_producer_fusion(hbmpc_ctx* ctx, int on);
 /* hbmpc_dev_fpmul_parties runs as one launch up to max_elements batch elements (default 2048; 0: always the five separate
  * launches).  Same bytes either way (A/B aid). */
 ShareErrorCode hbmpc_set_fused_fpmul(hbmpc_ctx* ctx, size_t max_elements);
+/* hbmpc_dev_fpmul_parties' five-launch form from min_elements batch elements on (default 8192; (size_t)-1: never): the first open
+ * forms the senders' a - x and b - y as the decode loads them instead of reading them back from a launch that wrote every
+ * party's (four launches; de_sh_ws is then left untouched).  Same bytes in every output (A/B aid). */
+ShareErrorCode hbmpc_set_fpmul_pair_decode(hbmpc_ctx* ctx, size_t min_elements);
 /* A decode that is given exactly d + t + 1 senders -- what BatchRecon passes: it decodes as soon as that many have
  * arrived (batch_recon.rs:371-389) -- has no OEC round: a chunk that fails the verification can only fail
  * (DecodingError, robust_interpolate.rs:625).  Such a call is ONE kernel launch: the decode kernel writes the failure

@@ -63,6 +63,7 @@ struct hbmpc_ctx {
     size_t mfma_min_encode = 2049;                 // encodes (one table per (n, d), never rebuilt): right above the wave-per-chunk range
     int lazy_fallback_tables = 1;                  // a new sender set's OEC / Gao and second-chance tables are built when a chunk needs them: 1 = host-pointer calls, 2 = all
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
+    size_t pair_decode_min = 8192;                // hbmpc_dev_fpmul_parties: from this many elements the first open forms its shares at load time
     size_t fused_fpmul_max = 2048;                 // hbmpc_dev_fpmul_parties: one launch (a wave per element) up to this many elements (0: never)
     bool gather_row_copies = false;                // hbmpc_dev_gather_party_major: take the per-row peer copies even where the 2-D copy applies (A/B aid)
     bool list_rows_in_kernel = true;               // the producers' mixing step writes the parties' lists itself (k_mfma_bfly<.., LISTS>)
@@ -86,6 +87,7 @@ static thread_local std::string g_err;
 // > 0 while the calling thread is between hbmpc_graph_begin_capture and _end_capture (capture mode is thread-local):
 // tables and scratch it looks up are then pinned for the graph's lifetime, and nothing may be allocated
 static thread_local int g_capturing = 0;
+static const ShareErrorCode HBMPC_NOT_FUSED = (ShareErrorCode)9999;  // internal: a fused form does not cover the call (nothing was enqueued)
 // internal: batch_recover_dev was asked to form the senders' values at load time and the call cannot take that form
 
 #define HIP_TRY(ctx, call)                                                                              \
@@ -364,6 +366,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
 extern "C" ShareErrorCode hbmpc_set_fused_fpmul(hbmpc_ctx* ctx, size_t max_elements) {
     if (!ctx) return InvalidInput;
     ctx->fused_fpmul_max = max_elements;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_fpmul_pair_decode(hbmpc_ctx* ctx, size_t min_elements) {
+    if (!ctx) return InvalidInput;
+    ctx->pair_decode_min = min_elements;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_gather_row_copies(hbmpc_ctx* ctx, int on) {  // either field
@@ -1963,9 +1970,19 @@ extern "C" ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* 
     }
     // the shares Multiply opens (multiplication.rs:417-426) and reconstruct_rbc's recover_secret of a - x and of b - y (:102-139):
     // ONE interpolation over the 2 N values of a sender row
-    ShareErrorCode rc = hbmpc_dev_beaver_open_shares_paired(ctx, a, b, x, y, N, n, de_sh_ws, stream);
-    if (rc != ShareSuccess) return rc;
-    rc = hbmpc_dev_batch_recover_p0(ctx, sender_ids, S, de_sh_ws, 2 * N, n, t, t, de_out, status_out, summary_first_dev, stream);
+    // Large batches: the shares are formed as the matrix-core decode loads them (kernels_mfma.hpp, k_mfma_rows<.., SUB>) -- 4 (2t + 1)
+    // loads per element instead of a launch that writes all n parties' two shares and a decode that reads 2t + 1 of them back
+    // (config 5: 0.14 + 0.065 ms -> 0.11; ahead from ~8 000 elements, tools/sweep_fused_fpmul.py).
+    ShareErrorCode rc = HBMPC_NOT_FUSED;
+    if (N >= ctx->pair_decode_min) {
+        PairInput pi = {(const uint32_t*)a, (const uint32_t*)b, (const uint32_t*)x, (const uint32_t*)y, N};
+        rc = batch_recover_dev(ctx, sender_ids, S, nullptr, 2 * N, n, t, t, de_out, nullptr, status_out, summary_first_dev, true, stream, 0, nullptr, false, &pi);
+    }
+    if (rc == HBMPC_NOT_FUSED) {
+        rc = hbmpc_dev_beaver_open_shares_paired(ctx, a, b, x, y, N, n, de_sh_ws, stream);
+        if (rc != ShareSuccess) return rc;
+        rc = hbmpc_dev_batch_recover_p0(ctx, sender_ids, S, de_sh_ws, 2 * N, n, t, t, de_out, status_out, summary_first_dev, stream);
+    }
     if (rc != ShareSuccess) return rc;
     // finalize_mul (:57-100), r' (truncpr.rs:277-283), the share TruncPr opens (:294-297), its open (truncpr.rs:215), the last step (:216-220)
     rc = hbmpc_dev_fpmul_middle(ctx, c, x, y, de_out, de_out + N, r_bits, r_int, k, m, N, n, z_out, r_dash_out, open_sh_out, stream);

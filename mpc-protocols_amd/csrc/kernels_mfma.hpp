@@ -160,6 +160,42 @@ HB_DEV void reduce_words(const uint64_t (&T)[4], uint32_t (&Rw)[4], const Half& 
     }
 }
 
+// a - x (mod r) of two canonical elements held as lane-pair halves: one 128-bit subtract per half, the low half's borrow (and, in
+// the same word, the carry its "+ r" would produce) to the high half, the sign back, r added where the difference was negative
+HB_DEV v4i sub_mod_r(const v4i& a, const v4i& x, const Half& H) {
+    uint32_t d[4], e[4], b, c;
+    d[0] = __builtin_subc((uint32_t)a[0], (uint32_t)x[0], 0u, &b);
+    d[1] = __builtin_subc((uint32_t)a[1], (uint32_t)x[1], b, &b);
+    d[2] = __builtin_subc((uint32_t)a[2], (uint32_t)x[2], b, &b);
+    d[3] = __builtin_subc((uint32_t)a[3], (uint32_t)x[3], b, &b);
+    // the low half: d + r's low words and that sum's carry (what the high half needs when the difference is negative)
+    e[0] = __builtin_addc(d[0], H.rw[0], 0u, &c);
+    e[1] = __builtin_addc(d[1], H.rw[1], c, &c);
+    e[2] = __builtin_addc(d[2], H.rw[2], c, &c);
+    e[3] = __builtin_addc(d[3], H.rw[3], c, &c);
+    const uint32_t lo = low_bcast(b | (c << 1));  // bit 0: the low half's borrow, bit 1: its "+ r" carry
+    // the high half takes the borrow in
+    uint32_t bb, b2;
+    const uint32_t bin = lo & 1u & H.hmask;
+    uint32_t f[4];
+    f[0] = __builtin_subc(d[0], bin, 0u, &bb);
+    f[1] = __builtin_subc(d[1], 0u, bb, &bb);
+    f[2] = __builtin_subc(d[2], 0u, bb, &bb);
+    f[3] = __builtin_subc(d[3], 0u, bb, &b2);
+    const uint32_t neg = high_bcast(b | b2);  // the 256-bit difference is negative (b and b2 are never both set)
+    // high half, negative: f + r's high words + the low half's carry
+    uint32_t g[4], cc;
+    const uint32_t cin = (lo >> 1) & H.hmask;
+    g[0] = __builtin_addc(f[0], H.rw[0], cin, &cc);
+    g[1] = __builtin_addc(f[1], H.rw[1], cc, &cc);
+    g[2] = __builtin_addc(f[2], H.rw[2], cc, &cc);
+    g[3] = __builtin_addc(f[3], H.rw[3], cc, &cc);
+    v4i r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (int)(neg ? (H.hmask ? g[j] : e[j]) : f[j]);
+    return r;
+}
+
 HB_DEV v4i flip(v4i x) {
     x[0] ^= 0x80808080, x[1] ^= 0x80808080, x[2] ^= 0x80808080, x[3] ^= 0x80808080;
     return x;
@@ -240,6 +276,11 @@ struct MfmaRowsArgs {
     // (share_gen.rs:199-203, ran_dou_sha/mod.rs:314-331: per party [k][row]); list_rows = 0: every row is party-major
     int list_row0, list_rows;
     uint32_t list_K;
+    // k_mfma_rows<.., SUB> (decode): the senders' values are DIFFERENCES formed as they are loaded (the shares Multiply opens,
+    // mul/multiplication.rs:417-426): chunk g < sub_half is in[row][g] - sub_x[row][g], chunk g >= sub_half is
+    // in2[row][g - sub_half] - sub_x2[row][g - sub_half]  (mod r); sub_half is a multiple of 32, rows are row_stride elements apart
+    const uint8_t *sub_x, *in2, *sub_x2;
+    size_t sub_half;
     struct ListSlice {
         uint8_t* dst;
         uint64_t stride;  // elements between the lists of consecutive parties
@@ -251,8 +292,11 @@ struct MfmaRowsArgs {
 // count -- hipcc can then count the stores issued after the next tile's loads and wait with vmcnt(#stores) at the tile
 // boundary; with a run-time trip count it waits for vmcnt(0), i.e. for every store of the tile to complete.
 // (The timing-only ablations and the software-pipelined row loop of rounds 2 and 3 live in tools/kernels_mfma_lab.hpp.)
-template <int M, int CG, int WAVES, int NR = 0>
+// SUB (decode, CG = 1, one role): the sender values are differences of two arrays formed after loading (MfmaRowsArgs::sub_x); the
+// raw operands of the NEXT tile wait in registers while the current tile is processed.
+template <int M, int CG, int WAVES, int NR = 0, bool SUB = false>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
+    static_assert(!SUB || CG == 1, "SUB instances walk single tiles");
     static_assert(M <= 15, "digit sums must stay below 0xff0000 (tables_mfma.hpp) and the sum below 2^273");
     constexpr int ROWB = M * 1024 + 128;
     constexpr int NT = 64 * WAVES;
@@ -350,13 +394,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
 #pragma unroll
             for (int i = 0; i < M; ++i) data[cg][i] = flip(data[cg][i]);
         }
+        const bool second = SUB && t * 32 >= a.sub_half;  // wave-uniform: sub_half is a multiple of the tile
         auto load_ys = [&](int r, v4i (&ys)[CG]) {  // claimed values of verify row r (table row index)
             uint32_t ri = (uint32_t)a.rows[M + r];
             asm volatile("" : "+s"(ri));  // recomputed at every use: hoisted out of the tile loop, the row bases of an
                                           // unrolled row loop (NR > 0) would take two SGPRs each and spill the scalar file
-            const uint8_t* base = a.in + (size_t)ri * a.row_stride * 32;
+            if constexpr (SUB) {
+                const size_t ro = (size_t)ri * a.row_stride * 32;
+                const uint32_t lo = (g[0] - (second ? (uint32_t)a.sub_half : 0u)) * 32u + 16u * h;
+                const v4i va = *reinterpret_cast<const v4i*>((second ? a.in2 : a.in) + ro + lo);
+                const v4i vx = *reinterpret_cast<const v4i*>((second ? a.sub_x2 : a.sub_x) + ro + lo);
+                ys[0] = sub_mod_r(va, vx, H);
+            } else {
+                const uint8_t* base = a.in + (size_t)ri * a.row_stride * 32;
 #pragma unroll
-            for (int cg = 0; cg < CG; ++cg) ys[cg] = *reinterpret_cast<const v4i*>(base + (g[cg] * 32u + 16u * h));
+                for (int cg = 0; cg < CG; ++cg) ys[cg] = *reinterpret_cast<const v4i*>(base + (g[cg] * 32u + 16u * h));
+            }
         };
         v4i ys_cur[CG], ys_next[CG];
         if (nver > 0) load_ys(role.row0, ys_cur);
@@ -407,8 +460,33 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_rows(MfmaRowsArgs a) {
         }
         give_verdict(bad, g, live);
     };
-    v4i setA[CG][M], setB[CG][M];
     size_t t = (size_t)wg_in_role * WAVES + wave;
+    if constexpr (SUB) {
+        // raw operands of the next tile in flight (2 M registers of 4), the current tile's differences in `cur`
+        v4i ra[M], rx[M], cur[1][M];
+        auto load_raw = [&](size_t tt) {
+            const bool sec = tt * 32 >= a.sub_half;
+            const size_t gi = tt * 32 + c, gc = gi < a.G ? gi : a.G - 1;
+            const uint32_t lo = (uint32_t)(gc - (sec ? a.sub_half : 0)) * 32u + 16u * h;
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const size_t ro = (size_t)a.rows[i] * a.row_stride * 32;
+                ra[i] = *reinterpret_cast<const v4i*>((sec ? a.in2 : a.in) + ro + lo);
+                rx[i] = *reinterpret_cast<const v4i*>((sec ? a.sub_x2 : a.sub_x) + ro + lo);
+            }
+        };
+        if (t < ntiles) load_raw(t);
+        while (t < ntiles) {
+#pragma unroll
+            for (int i = 0; i < M; ++i) cur[0][i] = sub_mod_r(ra[i], rx[i], H);
+            if (t + tstep < ntiles) load_raw(t + tstep);
+            process_tile(t, cur);
+            t += tstep;
+        }
+        if (a.direct) finish_direct(a.counters, a.summary);
+        return;
+    }
+    v4i setA[CG][M], setB[CG][M];
     if (t < ntiles) load_inputs(t, setA);
     // the tile loop: the input sets alternate, the loads of a wave's NEXT tile are issued before it starts on the current one
 #define HBMPC_MF_WALK(TILE)                                                \

@@ -173,6 +173,12 @@ HB_DEV typename F::E dot_row(const typename F::E (&y)[M], const uint32_t* __rest
     return F::acc_reduce(acc);
 }
 
+// The shares Multiply opens (mul/multiplication.rs:417-426) as the input of a decode that forms them itself: chunk g < N is a - x of
+// element g, chunk N + g is b - y, from a, b, x, y [party][N] (kernels_mfma.hpp, k_mfma_rows<.., SUB>; hbmpc_dev_fpmul_parties)
+struct PairInput {
+    const uint32_t *a, *b, *x, *y;
+    size_t N;
+};
 template <class F, int M, bool P0_ONLY>
 __global__ __launch_bounds__(256, 2) void k_batch_recover(RecoverArgs a) {
     using E = typename F::E;

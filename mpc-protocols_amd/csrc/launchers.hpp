@@ -66,11 +66,15 @@ bool launch_recover_a(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipS
 bool launch_recover_b(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 bool launch_recover_c(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 bool launch_recover_d(int m, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
+
 void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned grid, hipStream_t s);
 // matrix-core form of the constant-matrix maps (kernels_mfma.hpp), m = 2 .. 15; false when m is not instantiated there.
 // team: the workgroup-per-tile form for batches with fewer tiles than waves (kernels_mfma_team.hpp)
 namespace mf { struct MfmaRowsArgs; struct MfmaGlArgs; }
 bool launch_mfma_rows_gl(const mf::MfmaGlArgs& a, unsigned grid, int device, hipStream_t s);  // Goldilocks (kernels_mfma_gl.hpp)
+// the decode whose sender values are differences formed after loading (k_mfma_rows<.., SUB>), m = 2 .. 11
+bool mfma_sub_covers(int m);
+bool launch_mfma_rows_sub(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 bool launch_mfma_rows_a(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 bool launch_mfma_rows_b(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);
 bool launch_mfma_rows_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s, bool team = false);

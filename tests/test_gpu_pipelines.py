@@ -93,11 +93,12 @@ def test_fpmul_pipeline(pkg_eng, n, t, N, k, m, senders):
         assert GU.eq(out[p], O.truncpr_finalize(z[p], rd, c_open, m)[1])
 
 
-@pytest.mark.parametrize("n,t,N,k,m", [(16, 5, 1000, 16, 4), (7, 2, 333, 32, 16), (4, 1, 2048, 16, 0), (16, 5, 3000, 16, 4), (31, 10, 257, 24, 8), (40, 13, 130, 16, 4),
-                                       (64, 21, 66, 16, 1)])
+@pytest.mark.parametrize("n,t,N,k,m", [(16, 5, 1000, 16, 4), (16, 5, 1024, 16, 4), (7, 2, 333, 32, 16), (7, 2, 96, 16, 2), (4, 1, 2048, 16, 0), (16, 5, 3008, 16, 4), (31, 10, 256, 24, 8),
+                                       (10, 3, 32, 16, 4), (40, 13, 130, 16, 4), (64, 21, 66, 16, 1)])
 def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
     """FPMulNode for all parties in ONE launch (hbmpc_dev_fpmul_parties at a small batch: a wave per element,
-    csrc/kernels_fpmul_wave.hpp) against the five separate launches (hbmpc_set_fused_fpmul(ctx, 0)): every buffer a caller can
+    csrc/kernels_fpmul_wave.hpp) and in FOUR (large batches: the first open forms its senders' shares as it loads them,
+    hbmpc_set_fpmul_pair_decode) against the five separate launches (hbmpc_set_fused_fpmul(ctx, 0)): every buffer a caller can
     see -- the opened a - x | b - y, z, r', the shares TruncPr opens, the opened value, the output, the statuses -- byte for
     byte, on sharings of random field elements (the steps are algebra, not range-limited) of which one is inconsistent (its
     opens fail and count, the steps after them run on zero), eager and replayed as a graph."""
@@ -112,8 +113,11 @@ def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
     ins[0][0, 5] = ins[0][2, 5]                                     # and party 0's x share: a - x fails too
     res = {}
     try:
-        for fused in (1 << 20, 0):
+        never = (1 << 64) - 1
+        for form, (fused, pair_min) in {"one": (1 << 20, never), "four": (0, 0), "five": (0, never)}.items():
             assert eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(fused)) == 0
+            assert eng.L.hbmpc_set_fpmul_pair_decode(eng.ctx, C.c_size_t(pair_min)) == 0
+            eng.set_matrix_cores(True, 32 if form == "four" else 65536)   # four: the matrix-core decode from 32 chunks on
             fp = pkg.pipelines.FpMul(eng, n, t, N, k, m, stream=ts.cuda_stream)
             fp.upload(ins[0], ins[1], ins[2], ins[3], ins[4], np.ascontiguousarray(bits), ins[5])
             marker = O.fill_random(77, 2 * n * N).reshape(n, 2, N, 4)
@@ -121,7 +125,9 @@ def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
             with pytest.raises(RuntimeError):
                 fp.run(check=True)
             fp.run(check=False)
-            assert GU.eq(fp.download_named("desh", (n, 2, N)), marker) == (fused != 0), "which form ran"
+            wrote_desh = not GU.eq(fp.download_named("desh", (n, 2, N)), marker)
+            # (the four-launch form covers t + 1 <= 11 and batches that are whole 32-element tiles; others run all five)
+            assert wrote_desh == (form == "five" or (form == "four" and (t + 1 > 11 or N % 32 != 0))), "which form ran"
             got = {}
             for nm in names:
                 got[nm] = fp.download_named(nm, (N,) if nm in ("dop", "eop", "cop") else (n, N)).copy()
@@ -135,12 +141,15 @@ def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
             eng.h2d(fp.out, np.zeros((n, N, 4), dtype=np.uint64), ts.cuda_stream)
             fp.replay()
             assert GU.eq(fp.download("out"), got["out"])
-            res[fused] = got
+            res[form] = got
             fp.close()
-        for nm in names + ("status", "summary", "summary_first"):
-            assert np.array_equal(res[1 << 20][nm], res[0][nm]), nm
+        for form in ("one", "four"):
+            for nm in names + ("status", "summary", "summary_first"):
+                assert np.array_equal(res[form][nm], res["five"][nm]), (form, nm)
     finally:
         eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(2048))
+        eng.L.hbmpc_set_fpmul_pair_decode(eng.ctx, C.c_size_t(8192))
+        eng.set_matrix_cores(True, 65536)
 
 
 def test_fpmul_pipeline_as_hip_graph(pkg_eng):

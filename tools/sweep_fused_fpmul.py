@@ -37,7 +37,7 @@ def ev_time(fn, reps=30, warm=3, warm_seconds=0.15):
 
 
 def main():
-    sizes = [int(v) for v in sys.argv[1:]] or [64, 256, 1024, 2048, 4096, 8192, 16384]
+    sizes = [int(v) for v in sys.argv[1:]] or [64, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144]
     dev = torch.device("cuda", 0)
     eng = load_package().Engine(0)
     ts = torch.cuda.Stream(device=dev)
@@ -46,12 +46,18 @@ def main():
     stream = ts.cuda_stream
     n, t, k, m = 16, 5, 16, 4
     print(f"fpmul n={n} t={t} (k, f)=({k}, {m}); ms per multiplication batch: eager / replayed graph")
-    print(f"{'elements':>9} {'one eager':>12} {'one graph':>12} {'five eager':>12} {'five graph':>12}")
+    print(f"{'elements':>9} {'one eager':>12} {'one graph':>12} {'five eager':>12} {'five graph':>12} {'four eager':>12} {'four graph':>12}")
+    never = (1 << 64) - 1
     if True:
         for N in sizes:
             row = []
-            for fused in (1 << 30, 0):
+            # one launch (a wave per element) | five launches | four (the first open forms its senders' shares as it loads them)
+            for fused, pair_min in ((1 << 30, never), (0, never), (0, 0)):
+                if fused and N > 16384:  # a wave per element is far behind by then
+                    row += [float("nan")] * 2
+                    continue
                 eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(fused))
+                eng.L.hbmpc_set_fpmul_pair_decode(eng.ctx, C.c_size_t(pair_min))
                 fp = bench.setup_fpmul(eng, torch, dev, stream, n, t, N, k, m)
                 fp.run(check=True)
                 fp.run(check=False)
@@ -60,7 +66,7 @@ def main():
                 g = ev_time(fp.replay)
                 fp.close()
                 row += [e, g]
-            print(f"{N:9d} {row[0]:12.4f} {row[1]:12.4f} {row[2]:12.4f} {row[3]:12.4f}", flush=True)
+            print(f"{N:9d} " + " ".join(f"{v:12.4f}" for v in row), flush=True)
 
 
 if __name__ == "__main__":
