@@ -152,6 +152,51 @@ def test_fpmul_one_launch_equals_five(pkg_eng, n, t, N, k, m):
         eng.set_matrix_cores(True, 65536)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fpmul_forms_random(pkg_eng, seed):
+    """hbmpc_dev_fpmul_parties on random shapes (n, t, batch, k, m; whole tiles or not; a few inconsistent shares or none): the
+    one-, four- and five-launch forms leave the same bytes in every buffer, status and summary.  tools/soak_fpmul.py runs many
+    more seeds."""
+    import ctypes as C
+    pkg, eng = pkg_eng
+    rng = np.random.default_rng(0xF9 + seed)
+    n = int(rng.integers(4, 41))
+    t = int(rng.integers(1, (n - 1) // 3 + 1))
+    N = int(rng.choice([rng.integers(1, 200), 32 * rng.integers(1, 40), rng.integers(200, 2500)]))
+    k = int(rng.integers(2, 65))
+    m = int(rng.integers(0, min(k, 12) + 1))
+    ins = [share_all(O.fill_random(5000 + 10 * seed + j, N), n, t, 6000 + 10 * seed + j) for j in range(6)]
+    bits = np.stack([share_all(O.fill_random(7000 + 20 * seed + j, N), n, t, 8000 + 20 * seed + j) for j in range(m)], axis=1) if m else np.zeros((n, 0, N, 4), dtype=np.uint64)
+    for _ in range(int(rng.integers(0, 4))):       # a share of x, y, a, b, c or r_int among the senders is replaced by a neighbour's
+        j, p, i = int(rng.integers(0, 6)), int(rng.integers(0, 2 * t + 1)), int(rng.integers(0, N))
+        ins[j][p, i] = ins[j][(p + 1) % n, i]
+    never = (1 << 64) - 1
+    names = ("dop", "eop", "z", "rdash", "osh", "cop", "out")
+    res = {}
+    try:
+        for form, (fused, pair_min) in {"one": (1 << 20, never), "four": (0, 0), "five": (0, never)}.items():
+            eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(fused))
+            eng.L.hbmpc_set_fpmul_pair_decode(eng.ctx, C.c_size_t(pair_min))
+            eng.set_matrix_cores(True, 32 if form == "four" else 65536)
+            fp = pkg.pipelines.FpMul(eng, n, t, N, k, m)
+            fp.upload(ins[0], ins[1], ins[2], ins[3], ins[4], np.ascontiguousarray(bits), ins[5])
+            fp.run(check=False)
+            got = {nm: fp.download_named(nm, (N,) if nm in ("dop", "eop", "cop") else (n, N)).copy() for nm in names}
+            for nm, arr in (("status", np.zeros(2 * N, dtype=np.uint8)), ("summary", np.zeros(4, dtype=np.uint32)), ("summary_first", np.zeros(4, dtype=np.uint32))):
+                eng.d2h(arr, fp.buffer(nm)[0])
+                got[nm] = arr
+            eng.sync()
+            res[form] = got
+            fp.close()
+        for form in ("one", "four"):
+            for nm in names + ("status", "summary", "summary_first"):
+                assert np.array_equal(res[form][nm], res["five"][nm]), (seed, n, t, N, k, m, form, nm)
+    finally:
+        eng.L.hbmpc_set_fused_fpmul(eng.ctx, C.c_size_t(2048))
+        eng.L.hbmpc_set_fpmul_pair_decode(eng.ctx, C.c_size_t(8192))
+        eng.set_matrix_cores(True, 65536)
+
+
 def test_fpmul_pipeline_as_hip_graph(pkg_eng):
     """The whole fpmul call sequence captured once into a HIP graph (hbmpc_graph_*) and replayed on refilled
     buffers gives exactly what the eager calls give."""
