@@ -472,6 +472,17 @@ class Engine:
                                              C.c_size_t(k), C.c_size_t(m), C.c_size_t(N), C.c_size_t(parties),
                                              C.c_void_p(z_d), C.c_void_p(rdash_d), C.c_void_p(open_d), C.c_void_p(stream))
 
+    def dev_fpmul_parties(self, sender_ids, a_d, b_d, c_d, x_d, y_d, rbits_d, rint_d, k, m, N, n, t, de_ws_d, de_d, z_d, rdash_d, osh_d,
+                          cop_d, out_d, status_d=0, summary_first_d=0, summary_d=0, stream=0):
+        """FPMulNode for all n parties of this device in one call (hbmpc_dev_fpmul_parties): one launch for a small batch, four or
+        five otherwise; returns the ShareErrorCode"""
+        ids = (C.c_size_t * len(sender_ids))(*sender_ids)
+        return self.L.hbmpc_dev_fpmul_parties(self.ctx, ids, C.c_size_t(len(sender_ids)),
+                                              *(C.c_void_p(p) for p in (a_d, b_d, c_d, x_d, y_d, rbits_d, rint_d)),
+                                              C.c_size_t(k), C.c_size_t(m), C.c_size_t(N), C.c_size_t(n), C.c_size_t(t),
+                                              *(C.c_void_p(p) for p in (de_ws_d, de_d, z_d, rdash_d, osh_d, cop_d, out_d, status_d, summary_first_d, summary_d)),
+                                              C.c_void_p(stream))
+
     def dev_beaver_open_shares_paired(self, a_d, b_d, x_d, y_d, N, parties, de_d, stream=0):
         """de[party][0][N] = a - x, de[party][1][N] = b - y: one P(0) decode over 2 N values per sender opens both"""
         return self._f("dev_beaver_open_shares_paired")(self.ctx, C.c_void_p(a_d), C.c_void_p(b_d), C.c_void_p(x_d), C.c_void_p(y_d),

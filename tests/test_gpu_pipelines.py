@@ -197,6 +197,40 @@ def test_fpmul_forms_random(pkg_eng, seed):
         eng.set_matrix_cores(True, 65536)
 
 
+def test_fpmul_parties_rejects_bad_calls(pkg_eng):
+    """hbmpc_dev_fpmul_parties validates like the calls it replaces: k = 0 (2^(k-1)), m beyond the supported range, m whose byte
+    index the reference would read out of bounds, null buffers, n < 3t + 1, too few / duplicate / out-of-range senders -- all
+    InvalidInput (4); a Goldilocks context is TypeMismatch (5)."""
+    pkg, eng = pkg_eng
+    n, t, N, k, m = 7, 2, 64, 16, 4
+    fp = pkg.pipelines.FpMul(eng, n, t, N, k, m)
+    b = {nm: fp.buffer(nm)[0] for nm in ("ta", "tb", "tc", "x", "y", "rbits", "rint", "desh", "dop", "z", "rdash", "osh", "cop", "out", "status", "summary")}
+
+    def call(ids=tuple(range(2 * t + 1)), eng_=eng, **kw):
+        a = dict(b)
+        shape = dict(k=k, m=m, N=N, n=n, t=t)
+        for key, v in kw.items():
+            (shape if key in shape else a)[key] = v
+        return eng_.dev_fpmul_parties(list(ids), a["ta"], a["tb"], a["tc"], a["x"], a["y"], a["rbits"], a["rint"], shape["k"], shape["m"], shape["N"],
+                                      shape["n"], shape["t"], a["desh"], a["dop"], a["z"], a["rdash"], a["osh"], a["cop"], a["out"], a["status"], 0, a["summary"])
+
+    assert call() == 0
+    eng.sync()
+    assert call(k=0) == 4 and call(m=4097) == 4 and call(m=257) == 4 and call(N=0) == 4 and call(n=0) == 4 and call(n=256) == 4
+    for nm in ("ta", "tb", "tc", "x", "y", "rint", "rbits", "desh", "dop", "z", "rdash", "osh", "cop", "out"):
+        assert call(**{nm: 0}) == 4, nm
+    assert call(status=0, summary=0) == 0                      # both optional
+    assert call(t=3) == 4                                       # n < 3t + 1
+    assert call(ids=(0, 1, 2, 3)) == 4 and call(ids=(0, 1, 2, 3, 3)) == 4 and call(ids=(0, 1, 2, 3, 7)) == 4
+    eng.sync()
+    gl = pkg.Engine(0, field="goldilocks")
+    try:
+        assert call(eng_=gl) == 5
+    finally:
+        gl.close()
+    fp.close()
+
+
 def test_fpmul_pipeline_as_hip_graph(pkg_eng):
     """The whole fpmul call sequence captured once into a HIP graph (hbmpc_graph_*) and replayed on refilled
     buffers gives exactly what the eager calls give."""
