@@ -133,41 +133,9 @@ __global__ __launch_bounds__(256) void k_fpmul_wave(FpmulWaveArgs a) {
     }
     __syncthreads();
 
-    // Row `row` of the table times the chunk's M values y(i) (LDS limbs), the products shared by 2^lk adjacent lanes: lane s
-    // of them takes the terms i = s, s + 2^lk, ..; the carry-folded partial sums (columns < 2^30) are added across the quad by
-    // DPP and every lane reduces the total.  (Only lane 0's partial sum carries the bias of acc_zero.)
+    // a table row times the chunk's M values (LDS limbs), the products shared by 2^lk adjacent lanes (kernels_recover.hpp)
     auto dot = [&](auto&& y_of, const uint32_t* row, int lk, int sidx) -> E {
-        typename F::Acc acc;
-        F::acc_zero(acc);
-        if (sidx != 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) acc.c[i] = 0;
-        }
-        int pending = 0;
-        for (int i = sidx; i < M; i += 1 << lk) {
-            if (pending == F::MAX_DOT_TERMS) {
-                F::acc_fold(acc);
-                pending = 1;
-            }
-            F::acc_mac(acc, F::load_const(y_of(i)), row + i * 9);
-            ++pending;
-        }
-        F::acc_fold(acc);
-        if (lk >= 1) {
-#pragma unroll
-            for (int i = 0; i < 17; ++i) acc.c[i] = (uint32_t)acc.c[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[i], 0xB1, 0xf, 0xf, false);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[17], 0xB1, 0xf, 0xf, false);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(acc.c[17] >> 32), 0xB1, 0xf, 0xf, false);
-            acc.c[17] += ((uint64_t)hi << 32) | lo;
-        }
-        if (lk >= 2) {
-#pragma unroll
-            for (int i = 0; i < 17; ++i) acc.c[i] = (uint32_t)acc.c[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[i], 0x4E, 0xf, 0xf, false);
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[17], 0x4E, 0xf, 0xf, false);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(acc.c[17] >> 32), 0x4E, 0xf, 0xf, false);
-            acc.c[17] += ((uint64_t)hi << 32) | lo;
-        }
-        return F::acc_reduce(acc);
+        return dot_shared<F>([&](int i) { return F::load_const(y_of(i)); }, row, M, lk, sidx);
     };
     // ---- the first open: a - x in lanes 0 .. 31, b - y in lanes 32 .. 63; row r of the table per lane -----------------------
     // (r < nv verify rows; nv: P(0); nv + 1: P(0) R, what finalize_mul multiplies by)

@@ -522,11 +522,54 @@ __global__ __launch_bounds__(256, 2) void k_second_chance_m(SecondArgs a) {
 // the tables (a verify row or an output row): latency m products instead of (needed - m + out_width) m, at the price
 // of idle lanes, which is free while the chip is not full.  Same tables, same arithmetic, same results; the chunk's
 // sender values are staged once in the wave's slice of LDS, constants are read per lane.
+// One table row times the M values of a chunk with the products SHARED by 2^lk adjacent lanes (lk = 0, 1, 2; U29): lane s of
+// them takes the terms i = s, s + 2^lk, ..; the carry-folded partial sums (columns < 2^30) are added across the quad by DPP
+// (quad_perm [1,0,3,2], then [2,3,0,1]) and every lane reduces the total.  Only lane 0's partial sum carries the bias of
+// acc_zero.  A lone wave per SIMD issues a v_mad_u64_u32 every 16 cycles: the 81 m of a row's products are the latency of a
+// small decode, and the lanes that would idle take three quarters of them (profiles/r04_small_batch_fpmul.txt).
+// The lanes that share a row must be active together (whole pairs / quads).
+template <class F, class Y>
+HB_DEV typename F::E dot_shared(Y&& value_of, const uint32_t* row, int M, int lk, int sidx) {
+    static_assert(F::NL == 9, "the column layout of U29's accumulator");
+    typename F::Acc acc;
+    F::acc_zero(acc);
+    if (sidx != 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc.c[i] = 0;
+    }
+    int pending = 0;
+    for (int i = sidx; i < M; i += 1 << lk) {
+        if (pending == F::MAX_DOT_TERMS) {
+            F::acc_fold(acc);
+            pending = 1;
+        }
+        F::acc_mac(acc, value_of(i), row + i * F::NL);
+        ++pending;
+    }
+    F::acc_fold(acc);
+    if (lk >= 1) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) acc.c[i] = (uint32_t)acc.c[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[i], 0xB1, 0xf, 0xf, false);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[17], 0xB1, 0xf, 0xf, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(acc.c[17] >> 32), 0xB1, 0xf, 0xf, false);
+        acc.c[17] += ((uint64_t)hi << 32) | lo;
+    }
+    if (lk >= 2) {
+#pragma unroll
+        for (int i = 0; i < 17; ++i) acc.c[i] = (uint32_t)acc.c[i] + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[i], 0x4E, 0xf, 0xf, false);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)acc.c[17], 0x4E, 0xf, 0xf, false);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(acc.c[17] >> 32), 0x4E, 0xf, 0xf, false);
+        acc.c[17] += ((uint64_t)hi << 32) | lo;
+    }
+    return F::acc_reduce(acc);
+}
+
 struct WideArgs {
     RecoverArgs r;
     SecondArgs sc;  // used when fused != 0
     int fused;      // a chunk that fails the verification tries the second-chance candidates right here (same wave)
     int tab_words;  // TAB instances: (needed - m + out_width) * m constants, r.vm and r.bc contiguous, staged in LDS
+    int lk;         // U29 TAB instances: log2 of the lanes that share a row's products (dot_shared); > 0 only when every row fits the wave
 };
 // rows[i], i < 64, from the scalar side: a per-lane index into the argument struct compiles to a VECTOR load from the
 // argument segment -- a full memory round trip in front of the loads that depend on it; sixteen scalar words and a
@@ -606,7 +649,20 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     // first sweep: rows lane, of verify and output rows alike (an output row's value waits in registers for the vote)
     bool bad = false, have = false;
     E kept = F::zero();
-    if (lane < nv + ow) {
+    int row_of_mine = lane;
+    if constexpr (TAB && F::NL == 9) {
+        if (wa.lk > 0) {  // every row fits the wave with 2^lk lanes each (host): this sweep is the only one
+            const int sidx = lane & ((1 << wa.lk) - 1);
+            row_of_mine = lane >> wa.lk;
+            if (row_of_mine < nv + ow) {
+                kept = dot_shared<F>([&](int i) { return F::load(ys + i * F::EW); }, tab + (size_t)row_of_mine * M * F::NL, M, wa.lk, sidx);
+                if (row_of_mine < nv) bad = !F::eq_canon(F::canon_loose(kept), expect(row_of_mine));
+                else have = sidx == 0;
+            }
+            row_of_mine = sidx == 0 ? row_of_mine : nv + ow;  // the other lanes of a row own nothing
+        }
+    }
+    if ((!(TAB && F::NL == 9) || wa.lk == 0) && lane < nv + ow) {
         kept = dot(lane);
         if (lane < nv) bad = !F::eq_canon(F::canon_loose(kept), expect(lane));
         else have = true;
@@ -639,7 +695,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
         if (wa.fused) second_chance_wave<F>(wa.sc, g, a.counters + 2);
         return;
     }
-    if (have) F::store_loose(a.out + (g * (size_t)ow + (lane - nv)) * F::EW, kept);
+    if (have) F::store_loose(a.out + (g * (size_t)ow + (row_of_mine - nv)) * F::EW, kept);
     for (int r = lane + 64; r < nv + ow; r += 64)
         if (r >= nv) F::store_loose(a.out + (g * (size_t)ow + (r - nv)) * F::EW, dot(r));
     };

@@ -48,6 +48,11 @@ void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondA
     else memset(&wa.sc, 0, sizeof wa.sc);
     const size_t lds = wide_lds(impl, ra, p0, &wa.tab_words);
     const bool tab = wa.tab_words != 0;
+    wa.lk = 0;
+    if (tab && impl == 0) {  // U29: a row's products shared by up to four lanes while every row still fits the wave (dot_shared)
+        const int rows = (ra.needed - ra.m) + (p0 ? 1 : ra.m);
+        while (wa.lk < 2 && (rows << (wa.lk + 1)) <= 64 && (2 << wa.lk) <= ra.m) ++wa.lk;
+    }
 #define HBMPC_WIDE(F, P0) \
     do { \
         if (tab) hipLaunchKernelGGL((k_batch_recover_wide<F, P0, true>), dim3(grid), dim3(256), lds, s, wa); \
