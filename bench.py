@@ -1156,6 +1156,14 @@ def pipeline_measurements(eng, torch, dev, stream, ev_time):
     ms_graph = ev_time(fp.replay, reps=10, warm=2)
     res["cfg5_fpmul_16_parties"] = {"fpmuls_per_s": N / min(ms, ms_graph) * 1e3, "ms": ms, "ms_hip_graph": ms_graph, "elements": N, "k": k, "f": m}
     fp.close()
+    # the same with f = 16 fractional bits ("and f=16"): 16 bit shares per element and party instead of 4
+    fp = setup_fpmul(eng, torch, dev, stream, n, t, N, 32, 16)
+    torch.cuda.synchronize()
+    fp.run(check=True)
+    ms16 = ev_time(lambda: fp.run(check=False), reps=10, warm=2)
+    res["cfg5_fpmul_16_parties_f16"] = {"fpmuls_per_s": N / ms16 * 1e3, "ms": ms16, "elements": N, "k": 32, "f": 16,
+                                        "algorithmic_GBps": (n * N * 32 * (7 + 16 + 3) + (2 * t + 1) * 5 * N * 32) / (ms16 * 1e-3) / 1e9}
+    fp.close()
     # the regime the protocols actually run in: small batches, where the ~110 launches of one fpmul are launch-bound.
     # Eager hbmpc_dev_* calls vs the same sequence captured once into a HIP graph (hbmpc_graph_*) and replayed.
     Ns = 1024

@@ -72,6 +72,7 @@ struct hbmpc_ctx {
     size_t mfma_min_gold = 4096;                   // Goldilocks encodes (tiny tables, one workgroup kind): from this many chunks
     size_t mfma_min_gold_direct = 2048;            // Goldilocks decodes without OEC rounds (one launch): flat ~7 us against a wave-per-chunk kernel that grows
     size_t mfma_min_gold_oec = 8193;               // Goldilocks decodes with OEC rounds (four launches against the small-batch path's two): beyond its range
+    std::map<size_t, HFr> inv_pow2;                // (2^m)^-1 per m: a field inversion is ~20 us of host time, more than a small launch
     std::map<size_t, std::shared_ptr<DomainInv<HFr>>> dom_fr;  // per n: domain elements + inverse differences (tables.hpp), built once
     std::map<size_t, std::shared_ptr<DomainInv<HGl>>> dom_gl;
     int n_cus = 256;
@@ -282,6 +283,16 @@ static ElemConsts elem_consts(int impl, const HFr* c0 = nullptr, const HFr* c1_p
     return cs;
 }
 
+// (2^m)^-1, computed once per m and context (TruncPr's last step, truncpr.rs:216-220)
+static HFr inv_pow2(hbmpc_ctx* ctx, size_t m) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->inv_pow2.find(m);
+    if (it != ctx->inv_pow2.end()) return it->second;
+    if (ctx->inv_pow2.size() > 4096) ctx->inv_pow2.clear();
+    const HFr v = HFr::from_u64(2).pow_u64(m).inv();
+    ctx->inv_pow2.emplace(m, v);
+    return v;
+}
 // ---- context -----------------------------------------------------------------------------------
 extern "C" const char* hbmpc_version(void) { return "hbmpc-hip 0.1 (gfx950)"; }
 
@@ -1499,7 +1510,7 @@ static ShareErrorCode truncpr_finalize_impl(hbmpc_ctx* ctx, const U256* a, const
     if (ctx && m % 8 != 0 && m / 8 >= 32) return fail(ctx, InvalidInput, "m: bytes[m/8] out of bounds in the reference");
     ELEM_PROLOGUE
     CHECK_PARTIES(parties);
-    const HFr inv = HFr::from_u64(2).pow_u64(m).inv();
+    const HFr inv = inv_pow2(ctx, m);
     const ElemConsts cs = elem_consts(ctx->impl, &inv);
     BY_IMPL_P(parties, k_truncpr_finalize, W(a), W(r_dash), W(c_open), (int)(m > 256 ? 256 : m), N, cs, WO(d_out));
     return ShareSuccess;
@@ -1943,7 +1954,7 @@ extern "C" ShareErrorCode hbmpc_dev_fpmul_parties(hbmpc_ctx* ctx, const size_t* 
             rc = get_table(ctx, key("pow2", {m}, impl), [&] { return build_pow2(m, impl); }, &fa.pow2);
             if (rc != ShareSuccess) return rc;
             const HFr two = HFr::from_u64(2);
-            const HFr p2m = two.pow_u64(m), p2k = two.pow_u64(k - 1), inv = p2m.inv();
+            const HFr p2m = two.pow_u64(m), p2k = two.pow_u64(k - 1), inv = inv_pow2(ctx, m);
             const ElemConsts cs = elem_consts(impl, &p2m, &p2k), ci = elem_consts(impl, &inv);
             memcpy(fa.c0, cs.c0, sizeof fa.c0), memcpy(fa.c1, cs.c1, sizeof fa.c1), memcpy(fa.cinv, ci.c0, sizeof fa.cinv);
             fa.ta = (const uint32_t*)a, fa.tb = (const uint32_t*)b, fa.tc = (const uint32_t*)c, fa.x = (const uint32_t*)x, fa.y = (const uint32_t*)y;
