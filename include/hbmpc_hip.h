@@ -426,6 +426,20 @@ ShareErrorCode hbmpc_dev_fpmul_middle(hbmpc_ctx* ctx, const U256* c, const U256*
  * de_sh_out[party][0][N] = a - x, [party][1][N] = b - y.  One robust interpolation over 2 N values per sender
  * (hbmpc_dev_batch_recover_p0 with G = 2 N: the sender rows are the parties' rows of de_sh_out) then opens d and e
  * together -- one call instead of two; its output is d[N] followed by e[N]. */
+/* TripleGenNode for every party of this device in one call (triple_gen/triple_generation.rs:304-364): [ab - r]_2t = a_i b_i - r2t_i
+ * (:333-340) in chunks of 2t + 1, BatchRecon's encode for every recipient (batch_recon.rs:157-165), the recipients' P(0) decodes
+ * (:384-391), the coefficient decode of the n revealed values (:457-467) and [c]_t = rt_i + opened (:196-208).  a, b, r2t, rt, c_out:
+ * [party][N], N a multiple of 2t + 1 (G = N / (2t + 1) chunks); y_ws [party][recipient][G] and z_ws [recipient][G] are the messages
+ * of the two arms (written, as the separate calls write them); opened_out [G][2t + 1]; status_out [n G] as the two decodes leave it
+ * ([0, G) the second's, [G, n G) recipients 1 .. n - 1 of the first); the two decodes' summaries (either may be null).  A chunk that
+ * fails a decode opens to zero and is counted, and the steps after it run on that zero.
+ * With n = 3t + 1 <= 16 (every decode has exactly d + t + 1 senders) and at most hbmpc_set_fused_triplegen chunks (default 1024) the
+ * call is ONE launch, a workgroup per chunk (csrc/kernels_triplegen_wg.hpp); otherwise the four launches
+ * hbmpc_dev_triple_encode_parties (c_out is its workspace), hbmpc_dev_batch_recover_strided (P(0), n G chunks),
+ * hbmpc_dev_batch_recover, hbmpc_dev_triple_finalize_parties.  Same bytes in every buffer either way. */
+ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, const U256* rt, size_t N, size_t n,
+                                           size_t t, U256* y_ws, U256* z_ws, U256* opened_out, U256* c_out, uint8_t* status_out,
+                                           hbmpc_recover_summary* summary_first_dev, hbmpc_recover_summary* summary_dev, void* stream);
 /* FPMulNode for every party of this device in one call (fpmul/fpmul.rs:61-110): Multiply's opened a - x and b - y
  * (mul/multiplication.rs:417-426, :102-139), finalize_mul (:57-100), TruncPr's r' and opened share (truncpr.rs:277-297, :215) and
  * its last step (:216-220).  Per-party arrays are [party][N] (r_bits [party][m][N]); sender_ids[S] are PARTY ids, degree and
@@ -715,6 +729,9 @@ ShareErrorCode hbmpc_set_producer_fusion(hbmpc_ctx* ctx, int on);
 /* hbmpc_dev_fpmul_parties runs as one launch up to max_elements batch elements (default 2048; 0: always the five separate
  * launches).  Same bytes either way (A/B aid). */
 ShareErrorCode hbmpc_set_fused_fpmul(hbmpc_ctx* ctx, size_t max_elements);
+/* hbmpc_dev_triplegen_parties runs as one launch up to max_chunks chunks of 2t + 1 triples (default 1024; 0: always the four
+ * separate launches).  Same bytes either way (A/B aid). */
+ShareErrorCode hbmpc_set_fused_triplegen(hbmpc_ctx* ctx, size_t max_chunks);
 /* hbmpc_dev_fpmul_parties' five-launch form from min_elements batch elements on (default 8192; (size_t)-1: never): the first open
  * forms the senders' a - x and b - y as the decode loads them instead of reading them back from a launch that wrote every
  * party's (four launches; de_sh_ws is then left untouched).  Same bytes in every output (A/B aid). */

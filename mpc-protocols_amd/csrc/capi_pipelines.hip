@@ -156,6 +156,7 @@ struct TripleGen : hbmpc_pipe {
     size_t n, t, N, G;
     unsigned char *a, *b, *r2t, *rt, *c, *Y, *Z, *opened;
     uint8_t* status;
+    hbmpc_recover_summary* summ_first;  // the recipients' decodes' (summ: the revealed values')
     std::vector<size_t> ids;
     TripleGen(hbmpc_ctx* cx, size_t n_, size_t t_, size_t N_, void* s) : hbmpc_pipe(cx, s), n(n_), t(t_), N(N_), G(N_ / (2 * t_ + 1)) {
         if (n == 0 || N == 0 || N % (2 * t + 1) != 0) throw PipeError{InvalidInput};
@@ -166,10 +167,18 @@ struct TripleGen : hbmpc_pipe {
         opened = take("opened", N); // [G][2t+1] == flat [N]
         status = take_bytes("status", n * G, n * G);
         summ = reinterpret_cast<hbmpc_recover_summary*>(take_bytes("summary", 64, 16));
+        summ_first = reinterpret_cast<hbmpc_recover_summary*>(take_bytes("summary_first", 64, 16));
         for (size_t i = 0; i < n; ++i) ids.push_back(i);
     }
     void run() override {
         const size_t d = 2 * t;
+        if (!f.gl) {  // one call for the whole step: one launch for a small batch, the four below otherwise (hbmpc_dev_triplegen_parties)
+            PL(hbmpc_dev_triplegen_parties(ctx, (const U256*)a, (const U256*)b, (const U256*)r2t, (const U256*)rt, N, n, t, (U256*)Y, (U256*)Z,
+                                           (U256*)opened, (U256*)c, status, summ_first, summ, stream));
+            check_summary(summ_first);
+            check_summary(summ);
+            return;
+        }
         // [ab - r]_2t = a_i b_i - r2t_i (triple_generation.rs:333-340) Vandermonde-encoded in chunks of 2t+1 for every
         // recipient (batch_recon.rs:157-165): a, b, r2t [party][N] -> Y[party][n][G], all parties in ONE launch; the local
         // products stay on chip where the fused kernel covers the shape (c is the workspace of the two-launch path)

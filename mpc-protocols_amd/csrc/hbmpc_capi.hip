@@ -19,6 +19,7 @@
 #include "fr_gold.hpp"
 #include "kernels_elem.hpp"
 #include "kernels_fpmul_wave.hpp"
+#include "kernels_triplegen_wg.hpp"
 #include "launchers.hpp"
 #include "tables.hpp"
 #include "tables_mfma.hpp"
@@ -64,6 +65,7 @@ struct hbmpc_ctx {
     int lazy_fallback_tables = 1;                  // a new sender set's OEC / Gao and second-chance tables are built when a chunk needs them: 1 = host-pointer calls, 2 = all
     bool device_tables = true;                     // the matrix-core table of a new sender set is expanded on the device (kernels_tables.hpp)
     size_t pair_decode_min = 8192;                // hbmpc_dev_fpmul_parties: from this many elements the first open forms its shares at load time
+    size_t fused_triplegen_max = 1024;             // hbmpc_dev_triplegen_parties: one launch (a workgroup per chunk of 2t + 1 triples) up to this many chunks (0: never)
     size_t fused_fpmul_max = 2048;                 // hbmpc_dev_fpmul_parties: one launch (a wave per element) up to this many elements (0: never)
     bool gather_row_copies = false;                // hbmpc_dev_gather_party_major: take the per-row peer copies even where the 2-D copy applies (A/B aid)
     bool list_rows_in_kernel = true;               // the producers' mixing step writes the parties' lists itself (k_mfma_bfly<.., LISTS>)
@@ -377,6 +379,11 @@ extern "C" ShareErrorCode hbmpc_set_matrix_cores(hbmpc_ctx* ctx, int on, size_t 
 extern "C" ShareErrorCode hbmpc_set_fused_fpmul(hbmpc_ctx* ctx, size_t max_elements) {
     if (!ctx) return InvalidInput;
     ctx->fused_fpmul_max = max_elements;
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_set_fused_triplegen(hbmpc_ctx* ctx, size_t max_chunks) {
+    if (!ctx) return InvalidInput;
+    ctx->fused_triplegen_max = max_chunks;
     return ShareSuccess;
 }
 extern "C" ShareErrorCode hbmpc_set_fpmul_pair_decode(hbmpc_ctx* ctx, size_t min_elements) {
@@ -1902,6 +1909,78 @@ extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const 
 }
 
 #include "capi_recover.inc"
+
+// ---- TripleGenNode for all parties on this device (triple_gen/triple_generation.rs:304-364) --------------------------------------
+extern "C" ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, const U256* rt, size_t N,
+                                                      size_t n, size_t t, U256* y_ws, U256* z_ws, U256* opened_out, U256* c_out, uint8_t* status_out,
+                                                      hbmpc_recover_summary* summary_first_dev, hbmpc_recover_summary* summary_dev, void* stream) {
+    REQ_FR(ctx);
+    if (!a || !b || !r2t || !rt || !y_ws || !z_ws || !opened_out || !c_out) return fail(ctx, InvalidInput, "null buffer");
+    const size_t M = 2 * t + 1, d = 2 * t;
+    if (N == 0 || n == 0 || n > 255 || N % M != 0) return fail(ctx, InvalidInput, "N must be a positive multiple of 2t + 1; n in 1 .. 255");
+    if (n < 3 * t + 1) return fail(ctx, InvalidInput, "n must be >= 3t + 1 for Byzantine fault tolerance");
+    const size_t G = N / M;
+    std::vector<size_t> ids(n);
+    for (size_t i = 0; i < n; ++i) ids[i] = i;
+    // Small batches: one launch, a workgroup per chunk (kernels_triplegen_wg.hpp).  n = 3t + 1 <= 16: every recipient decodes from
+    // exactly d + t + 1 senders (no OEC round), and the (party, recipient) pairs fit the workgroup.
+    if (G <= ctx->fused_triplegen_max && n == 3 * t + 1 && n <= 16 && ctx->impl == IMPL_U29 && !ctx->force_generic && ctx->direct_fail) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = pick(ctx, stream);
+        const int impl = ctx->impl;
+        TripleGenWgArgs ta;
+        memset(&ta, 0, sizeof ta);
+        const std::shared_ptr<const DomainInv<HFr>> dom = domain_inv<HFr>(ctx, n);
+        ShareErrorCode rc = get_table(ctx, ids_key("rec", ids, n, n, d, t, impl), [&] {
+            RecoverTables T = build_recover_tables<HFr>(*dom, ids, d, t, impl);
+            std::vector<uint32_t> both = T.vm;
+            both.insert(both.end(), T.bc.begin(), T.bc.end());
+            return both;
+        }, &ta.tab);
+        if (rc != ShareSuccess) return rc;
+        rc = get_table(ctx, key("vmat", {n, d}, impl), [&] {
+            std::vector<uint32_t> w;
+            for (const HFr& al : domain_elements<HFr>(n, n)) {
+                HFr p = HFr::one();
+                for (size_t k = 0; k <= d; ++k) {
+                    put_const(w, p, impl);
+                    p = p * al;
+                }
+            }
+            return w;
+        }, &ta.vmat);
+        if (rc != ShareSuccess) return rc;
+        const ElemConsts cs = elem_consts(impl);
+        memcpy(ta.r2, cs.r2, sizeof ta.r2);
+        ta.a = (const uint32_t*)a, ta.b = (const uint32_t*)b, ta.r2t = (const uint32_t*)r2t, ta.rt = (const uint32_t*)rt;
+        ta.Y = (uint32_t*)y_ws, ta.Z = (uint32_t*)z_ws, ta.opened = (uint32_t*)opened_out, ta.c = (uint32_t*)c_out, ta.status = status_out;
+        ta.G = G, ta.N = N, ta.n = (int)n, ta.t = (int)t;
+        std::lock_guard<std::mutex> enqueue_lock(ctx->enqueue_mu);
+        void* scratch;
+        bool dirty = false;
+        rc = get_scratch(ctx, s, 2048, &scratch, &dirty);
+        if (rc != ShareSuccess) return rc;
+        ta.counters = (uint32_t*)scratch;
+        ta.summary_first = summary_first_dev ? (uint32_t*)summary_first_dev : ta.counters + 4;
+        ta.summary = summary_dev ? (uint32_t*)summary_dev : ta.counters + 4;
+        if (dirty) HIP_TRY(ctx, hipMemsetAsync(ta.counters, 0, 128, s));
+        set_scratch_dirty(ctx, s, true);
+        launch_triplegen_wg(ta, s);
+        HIP_TRY(ctx, hipGetLastError());
+        set_scratch_dirty(ctx, s, false);  // the kernel's last workgroup leaves the counters at zero
+        return ShareSuccess;
+    }
+    // [ab - r]_2t Vandermonde-encoded in chunks of 2t + 1 for every recipient (batch_recon.rs:157-165), all parties in one launch
+    ShareErrorCode rc = hbmpc_dev_triple_encode_parties(ctx, a, b, r2t, G, n, d, n, c_out, y_ws, stream);
+    if (rc != ShareSuccess) return rc;
+    // EvalBatch arm for ALL recipients in one call: the row of sender p for "chunk" j G + g is y_ws + p (n G) + (j G + g)
+    rc = hbmpc_dev_batch_recover_strided(ctx, ids.data(), n, y_ws, n * G, n * G, n, d, t, 1, z_ws, nullptr, status_out, summary_first_dev, stream);
+    if (rc != ShareSuccess) return rc;
+    // RevealBatch arm: everyone interpolates the 2t + 1 opened values per chunk from the n broadcast values
+    rc = hbmpc_dev_batch_recover(ctx, ids.data(), n, z_ws, G, n, d, t, opened_out, nullptr, status_out, summary_dev, stream);
+    if (rc != ShareSuccess) return rc;
+    return hbmpc_dev_triple_finalize_parties(ctx, rt, opened_out, N, n, c_out, stream);  // [c]_t = rt_i + opened (triple_generation.rs:196-208)
+}
 
 // ---- FPMulNode for all parties on this device (fpmul/fpmul.rs:61-110) ----------------------------------------------------------
 // The table of k_fpmul_wave: the verify rows and the P(0) row of the decode's table, and the P(0) row scaled by R (its

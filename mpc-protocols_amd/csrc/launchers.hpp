@@ -90,6 +90,8 @@ void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, con
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);
 // FPMulNode for all parties of a small batch in one launch (kernels_fpmul_wave.hpp); false: the shape does not fit a workgroup's LDS
 struct FpmulWaveArgs;
+struct TripleGenWgArgs;
+void launch_triplegen_wg(const TripleGenWgArgs& a, hipStream_t s);  // TripleGenNode, a workgroup per chunk (kernels_triplegen_wg.hpp)
 bool launch_fpmul_wave(const FpmulWaveArgs& a, int device, hipStream_t s, bool dry_run);
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);

@@ -57,6 +57,69 @@ def test_triple_gen_pipeline(pkg_eng, n, t, groups):
         assert GU.eq(c[p], O.triple_finalize(srt[p], opened)[1])
 
 
+def _triplegen_forms(pkg, eng, n, t, groups, seed, tamper):
+    """TripleGen through hbmpc_dev_triplegen_parties as one launch and as four: every visible buffer of both"""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    st = torch.cuda.Stream(device=torch.device("cuda", 0)).cuda_stream
+    N = groups * (2 * t + 1)
+    a, b, r = O.fill_random(seed, N), O.fill_random(seed + 1, N), O.fill_random(seed + 2, N)
+    ins = {"a": share_all(a, n, t, seed + 3), "b": share_all(b, n, t, seed + 4), "r2t": share_all(r, n, 2 * t, seed + 5), "rt": share_all(r, n, t, seed + 6)}
+    for nm, p, i in tamper:
+        ins[nm][p, i] = ins[nm][(p + 1) % n, i]
+    res = {}
+    try:
+        for form, fused in (("one", 1 << 20), ("four", 0)):
+            assert eng.L.hbmpc_set_fused_triplegen(eng.ctx, C.c_size_t(fused)) == 0
+            tg = pkg.pipelines.TripleGen(eng, n, t, N, stream=st)
+            tg.upload(ins["a"], ins["b"], ins["r2t"], ins["rt"])
+            tg.run(check=False)
+            got = {"c": tg.download_c().copy(), "Y": tg.download_named("Y", (n, n, groups)).copy(), "Z": tg.download_named("Z", (n, groups)).copy(),
+                   "opened": tg.download_named("opened", (N,)).copy()}
+            for nm, arr in (("status", np.zeros(n * groups, dtype=np.uint8)), ("summary", np.zeros(4, dtype=np.uint32)), ("summary_first", np.zeros(4, dtype=np.uint32))):
+                eng.d2h(arr, tg.buffer(nm)[0], st)
+                got[nm] = arr
+            eng.sync(st)
+            tg.capture()
+            eng.h2d(tg.c, np.zeros((n, N, 4), dtype=np.uint64), st)
+            tg.replay()
+            assert GU.eq(tg.download_c(), got["c"])
+            res[form] = got
+            tg.close()
+    finally:
+        eng.L.hbmpc_set_fused_triplegen(eng.ctx, C.c_size_t(1024))
+    for nm in res["four"]:
+        assert np.array_equal(res["one"][nm], res["four"][nm]), (n, t, groups, nm)
+    return res["one"], (a, b, r)
+
+
+@pytest.mark.parametrize("n,t,groups", [(4, 1, 5), (7, 2, 40), (10, 3, 33), (13, 4, 17), (16, 5, 100)])
+def test_triplegen_one_launch_equals_four(pkg_eng, n, t, groups):
+    """TripleGenNode for all parties in ONE launch (hbmpc_dev_triplegen_parties at a small batch: a workgroup per chunk,
+    csrc/kernels_triplegen_wg.hpp) against the four separate launches (hbmpc_set_fused_triplegen(ctx, 0)): the messages of both
+    arms, the opened values, the output shares, statuses and summaries byte for byte -- honest, then with shares replaced (the
+    recipients' decodes of a chunk fail and count, the steps after them run on zero) -- eager and replayed as a graph."""
+    pkg, eng = pkg_eng
+    got, (a, b, r) = _triplegen_forms(pkg, eng, n, t, groups, 300 + n, [])
+    assert got["summary"].tolist() == [0, 0, 0xffffffff, 0] and got["summary_first"].tolist() == [0, 0, 0xffffffff, 0]
+    assert GU.eq(open_all(got["c"], n, t, t), O.fr_binop("mul", a, b))
+    m = 2 * t + 1
+    bad, _ = _triplegen_forms(pkg, eng, n, t, groups, 300 + n, [("a", 1, 2 * m + 1), ("r2t", 0, 0)])
+    assert bad["summary_first"][0] > 0 and bad["status"][groups:].any()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_triplegen_forms_random(pkg_eng, seed):
+    """the same on random (t, number of chunks, a few replaced shares or none); tools/soak_triplegen.py runs many more seeds"""
+    pkg, eng = pkg_eng
+    rng = np.random.default_rng(0x7E + seed)
+    t = int(rng.integers(1, 6))
+    n, groups = 3 * t + 1, int(rng.integers(1, 130))
+    N = groups * (2 * t + 1)
+    tamper = [(str(rng.choice(["a", "b", "r2t", "rt"])), int(rng.integers(0, n)), int(rng.integers(0, N))) for _ in range(int(rng.integers(0, 3)))]
+    _triplegen_forms(pkg, eng, n, t, groups, 9000 + 10 * seed, tamper)
+
+
 @pytest.mark.parametrize("senders", ["2t+1", "n"])   # the reference opens from the first 2t+1 arrivals; n: OEC rounds available
 @pytest.mark.parametrize("n,t,N,k,m", [(4, 1, 50, 16, 4), (7, 2, 64, 16, 4), (16, 5, 200, 32, 16)])
 def test_fpmul_pipeline(pkg_eng, n, t, N, k, m, senders):
