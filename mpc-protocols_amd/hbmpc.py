@@ -472,6 +472,12 @@ class Engine:
                                              C.c_size_t(k), C.c_size_t(m), C.c_size_t(N), C.c_size_t(parties),
                                              C.c_void_p(z_d), C.c_void_p(rdash_d), C.c_void_p(open_d), C.c_void_p(stream))
 
+    def dev_triplegen_parties(self, a_d, b_d, r2t_d, rt_d, N, n, t, y_d, z_d, opened_d, c_d, status_d=0, summary_first_d=0, summary_d=0, stream=0):
+        """TripleGenNode for all n parties of this device in one call (hbmpc_dev_triplegen_parties): one launch for a small batch, four
+        otherwise; returns the ShareErrorCode"""
+        return self.L.hbmpc_dev_triplegen_parties(self.ctx, *(C.c_void_p(p) for p in (a_d, b_d, r2t_d, rt_d)), C.c_size_t(N), C.c_size_t(n), C.c_size_t(t),
+                                                  *(C.c_void_p(p) for p in (y_d, z_d, opened_d, c_d, status_d, summary_first_d, summary_d)), C.c_void_p(stream))
+
     def dev_fpmul_parties(self, sender_ids, a_d, b_d, c_d, x_d, y_d, rbits_d, rint_d, k, m, N, n, t, de_ws_d, de_d, z_d, rdash_d, osh_d,
                           cop_d, out_d, status_d=0, summary_first_d=0, summary_d=0, stream=0):
         """FPMulNode for all n parties of this device in one call (hbmpc_dev_fpmul_parties): one launch for a small batch, four or

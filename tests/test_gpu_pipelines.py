@@ -260,6 +260,32 @@ def test_fpmul_forms_random(pkg_eng, seed):
         eng.set_matrix_cores(True, 65536)
 
 
+def test_triplegen_parties_rejects_bad_calls(pkg_eng):
+    """hbmpc_dev_triplegen_parties: null buffers, N not a positive multiple of 2t + 1, n out of range or below 3t + 1 -- InvalidInput (4);
+    a Goldilocks context is TypeMismatch (5); the optional status and summaries may be null"""
+    pkg, eng = pkg_eng
+    n, t, groups = 7, 2, 6
+    N = groups * (2 * t + 1)
+    tg = pkg.pipelines.TripleGen(eng, n, t, N)
+    b = {nm: tg.buffer(nm)[0] for nm in ("a", "b", "r2t", "rt", "Y", "Z", "opened", "c", "status", "summary")}
+
+    def call(eng_=eng, N_=N, n_=n, t_=t, **kw):
+        a = dict(b, **kw)
+        return eng_.dev_triplegen_parties(a["a"], a["b"], a["r2t"], a["rt"], N_, n_, t_, a["Y"], a["Z"], a["opened"], a["c"], a["status"], 0, a["summary"])
+
+    assert call() == 0 and call(status=0, summary=0) == 0
+    eng.sync()
+    for nm in ("a", "b", "r2t", "rt", "Y", "Z", "opened", "c"):
+        assert call(**{nm: 0}) == 4, nm
+    assert call(N_=0) == 4 and call(N_=N + 1) == 4 and call(n_=0) == 4 and call(n_=256) == 4 and call(t_=3, N_=7 * 6) == 4
+    gl = pkg.Engine(0, field="goldilocks")
+    try:
+        assert call(eng_=gl) == 5
+    finally:
+        gl.close()
+    tg.close()
+
+
 def test_fpmul_parties_rejects_bad_calls(pkg_eng):
     """hbmpc_dev_fpmul_parties validates like the calls it replaces: k = 0 (2^(k-1)), m beyond the supported range, m whose byte
     index the reference would read out of bounds, null buffers, n < 3t + 1, too few / duplicate / out-of-range senders -- all
