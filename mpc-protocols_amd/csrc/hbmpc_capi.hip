@@ -776,6 +776,21 @@ static bool try_mfma_eval_gl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t
     return true;
 }
 
+// alpha_j^k, j < n, k <= d, as constants [n][d + 1] (k_eval_wide_dot, k_triplegen_wg)
+static ShareErrorCode vmat_table(hbmpc_ctx* ctx, size_t n, size_t d, const uint32_t** out) {
+    const int impl = ctx->impl;
+    return get_table(ctx, key("vmat", {n, d}, impl), [&] {
+        std::vector<uint32_t> w;
+        for (const HFr& al : domain_elements<HFr>(n, n)) {
+            HFr p = HFr::one();
+            for (size_t k = 0; k <= d; ++k) {
+                put_const(w, p, impl);
+                p = p * al;
+            }
+        }
+        return w;
+    }, out);
+}
 static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t d, EvalOut y,
                                 hipStream_t s) {
     const size_t size = domain_size(n), dp1 = d + 1;
@@ -783,6 +798,13 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
     const int impl = ctx->impl;
     const bool gold = impl == IMPL_GOLD;
     if (G * y.parties <= ctx->wide_max_chunks / 4 && !ctx->force_generic) {  // small batch: wave per chunk
+        if (impl == IMPL_U29 && n * dp1 * 36 <= 48 * 1024) {  // as a table product, the lanes sharing a point's terms (k_eval_wide_dot)
+            const uint32_t* vmat;
+            ShareErrorCode rc = vmat_table(ctx, n, d, &vmat);
+            if (rc != ShareSuccess) return rc;
+            launch_eval_wide_dot(x, G, (int)n, (int)dp1, vmat, y, s);
+            return ShareSuccess;
+        }
         const uint32_t* alpha;
         ShareErrorCode rc = get_table(ctx, key("alpha", {n}, impl), [&] {
             return gold ? build_alpha<HGl>(n, impl) : build_alpha<HFr>(n, impl);
@@ -1938,17 +1960,7 @@ extern "C" ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256
             return both;
         }, &ta.tab);
         if (rc != ShareSuccess) return rc;
-        rc = get_table(ctx, key("vmat", {n, d}, impl), [&] {
-            std::vector<uint32_t> w;
-            for (const HFr& al : domain_elements<HFr>(n, n)) {
-                HFr p = HFr::one();
-                for (size_t k = 0; k <= d; ++k) {
-                    put_const(w, p, impl);
-                    p = p * al;
-                }
-            }
-            return w;
-        }, &ta.vmat);
+        rc = vmat_table(ctx, n, d, &ta.vmat);
         if (rc != ShareSuccess) return rc;
         const ElemConsts cs = elem_consts(impl);
         memcpy(ta.r2, cs.r2, sizeof ta.r2);

@@ -24,6 +24,7 @@
 
 #include "fr_sat.hpp"
 #include "fr_u29.hpp"
+#include "kernels_recover.hpp"
 
 namespace hbmpc {
 
@@ -418,6 +419,33 @@ __global__ __launch_bounds__(256) void k_eval_wide(const uint32_t* __restrict__ 
             acc = F::add(acc, F::load(row + (size_t)k * F::EW));
         }
         F::store_loose(y + ((size_t)j * ys + g) * F::EW, acc);
+    }
+}
+
+// The same for U29 as a table product: a wave per chunk, 2^lk lanes per evaluation point j, y_j = sum_k alpha_j^k x_k with the
+// constants alpha_j^k staged in LDS once per workgroup (vmat [n][dp1]) -- depth ceil(dp1 / 2^lk) x 81 + 72 dependent
+// v_mad_u64_u32 instead of Horner's (dp1 - 1) x 153 (n = 16, d = 5, four lanes per point: 234 against 765; a lone wave per SIMD
+// issues one every 16 cycles, profiles/r04_small_batch_fpmul.txt).  dot_shared: kernels_recover.hpp.
+template <class F>
+__global__ __launch_bounds__(256) void k_eval_wide_dot(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
+                                                       const uint32_t* __restrict__ vmat, uint32_t* __restrict__ y, size_t ys, int lk) {
+    using E = typename F::E;
+    extern __shared__ __attribute__((aligned(16))) uint32_t vm[];
+    for (int w = threadIdx.x; w < n * dp1 * F::NL; w += 256) vm[w] = vmat[w];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    x += (size_t)blockIdx.y * G * dp1 * F::EW;
+    y += (size_t)blockIdx.y * n * ys * F::EW;
+    const uint32_t* row = x + g * (size_t)dp1 * F::EW;
+    const int sidx = lane & ((1 << lk) - 1), per = 64 >> lk;
+    for (int j0 = 0; j0 < n; j0 += per) {  // whole groups of 2^lk lanes share a point: in or out together
+        const int j = j0 + (lane >> lk);
+        if (j < n) {
+            const E v = dot_shared<F>([&](int k) { return F::load(row + (size_t)k * F::EW); }, vm + (size_t)j * dp1 * F::NL, dp1, lk, sidx);
+            if (sidx == 0) F::store_loose(y + ((size_t)j * ys + g) * F::EW, v);
+        }
     }
 }
 

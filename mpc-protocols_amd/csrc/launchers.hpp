@@ -87,6 +87,7 @@ bool launch_mfma_bfly_c(int m, const mf::MfmaRowsArgs& a, int device, hipStream_
 bool launch_mfma_bfly_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_t s);
 // small batches: one wave per chunk, one evaluation point / one table row per lane (k_eval_wide, k_batch_recover_wide)
 void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s);
+void launch_eval_wide_dot(const uint32_t* x, size_t G, int n, int dp1, const uint32_t* vmat, EvalOut y, hipStream_t s);  // U29, vmat [n][dp1] <= 48 KB
 void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);
 // FPMulNode for all parties of a small batch in one launch (kernels_fpmul_wave.hpp); false: the shape does not fit a workgroup's LDS
 struct FpmulWaveArgs;

@@ -10,6 +10,12 @@ void launch_eval_generic(int impl, const uint32_t* x, size_t G, int n, int dp1, 
     else if (impl == 1) hipLaunchKernelGGL((k_eval_generic<Sat32>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
     else hipLaunchKernelGGL((k_eval_generic<Gold>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
 }
+void launch_eval_wide_dot(const uint32_t* x, size_t G, int n, int dp1, const uint32_t* vmat, EvalOut y, hipStream_t s) {
+    const unsigned grid = (unsigned)((G + 3) / 4);
+    int lk = 0;
+    while (lk < 2 && (n << (lk + 1)) <= 64 && (2 << lk) <= dp1) ++lk;
+    hipLaunchKernelGGL((k_eval_wide_dot<U29>), dim3(grid, y.parties), dim3(256), (size_t)n * dp1 * U29::NL * 4, s, x, G, n, dp1, vmat, y.y, y.ys ? y.ys : G, lk);
+}
 void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s) {
     const unsigned grid = (unsigned)((G + 3) / 4);
     if (impl == 0) hipLaunchKernelGGL((k_eval_wide<U29>), dim3(grid, y.parties), dim3(256), 0, s, x, G, n, dp1, alpha, y.y, y.ys ? y.ys : G);
