@@ -672,6 +672,12 @@ ShareErrorCode hbmpc_gl_dev_beaver_open_shares(hbmpc_ctx* ctx, const uint64_t* a
                                                void* stream);
 ShareErrorCode hbmpc_gl_dev_triple_finalize_parties(hbmpc_ctx* ctx, const uint64_t* rt, const uint64_t* opened, size_t N,
                                                     size_t parties, uint64_t* c_out, void* stream);
+/* hbmpc_dev_triplegen_parties over the small field (PreprocNodesSmallField, honeybadger/mod.rs:316-324): same arguments, 8-byte
+ * elements; one launch under the same conditions up to half as many chunks (0.011 ms for 1 100 triples per party, four launches 0.029). */
+ShareErrorCode hbmpc_gl_dev_triplegen_parties(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, const uint64_t* rt, size_t N,
+                                              size_t n, size_t t, uint64_t* y_ws, uint64_t* z_ws, uint64_t* opened_out, uint64_t* c_out,
+                                              uint8_t* status_out, hbmpc_recover_summary* summary_first_dev, hbmpc_recover_summary* summary_dev,
+                                              void* stream);
 ShareErrorCode hbmpc_gl_dev_beaver_finalize_parties(hbmpc_ctx* ctx, const uint64_t* c, const uint64_t* x, const uint64_t* y,
                                                     const uint64_t* d, const uint64_t* e, size_t N, size_t parties,
                                                     uint64_t* z_out, void* stream);

@@ -171,27 +171,15 @@ struct TripleGen : hbmpc_pipe {
         for (size_t i = 0; i < n; ++i) ids.push_back(i);
     }
     void run() override {
-        const size_t d = 2 * t;
-        if (!f.gl) {  // one call for the whole step: one launch for a small batch, the four below otherwise (hbmpc_dev_triplegen_parties)
+        // one call for the whole step: one launch for a small batch, four otherwise (hbmpc_[gl_]dev_triplegen_parties)
+        if (f.gl)
+            PL(hbmpc_gl_dev_triplegen_parties(ctx, (const uint64_t*)a, (const uint64_t*)b, (const uint64_t*)r2t, (const uint64_t*)rt, N, n, t, (uint64_t*)Y,
+                                              (uint64_t*)Z, (uint64_t*)opened, (uint64_t*)c, status, summ_first, summ, stream));
+        else
             PL(hbmpc_dev_triplegen_parties(ctx, (const U256*)a, (const U256*)b, (const U256*)r2t, (const U256*)rt, N, n, t, (U256*)Y, (U256*)Z,
                                            (U256*)opened, (U256*)c, status, summ_first, summ, stream));
-            check_summary(summ_first);
-            check_summary(summ);
-            return;
-        }
-        // [ab - r]_2t = a_i b_i - r2t_i (triple_generation.rs:333-340) Vandermonde-encoded in chunks of 2t+1 for every
-        // recipient (batch_recon.rs:157-165): a, b, r2t [party][N] -> Y[party][n][G], all parties in ONE launch; the local
-        // products stay on chip where the fused kernel covers the shape (c is the workspace of the two-launch path)
-        PL(f.triple_encode(ctx, a, b, r2t, G, n, d, n, c, Y, stream));
-        // EvalBatch arm for ALL recipients in one call: with Y[p][j][g] the row of sender p for "chunk" j G + g is
-        // Y + p (n G) + (j G + g), and the output is already Z[j][g]
-        PL(f.recover_strided(ctx, ids.data(), n, Y, n * G, n * G, n, d, t, 1, Z, nullptr, status, summ, stream));
-        check_summary();
-        // RevealBatch arm: everyone interpolates the 2t+1 opened values per chunk from the n broadcast y_j
-        PL(f.recover(ctx, ids.data(), n, Z, G, n, d, t, opened, nullptr, status, summ, stream));
-        check_summary();
-        // [c]_t = rt_i + opened  (triple_generation.rs:196-208), all parties in one launch
-        PL(f.triple_finalize(ctx, rt, opened, N, n, c, stream));
+        check_summary(summ_first);
+        check_summary(summ);
     }
 };
 

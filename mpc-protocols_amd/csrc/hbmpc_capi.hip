@@ -777,12 +777,13 @@ static bool try_mfma_eval_gl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t
 }
 
 // alpha_j^k, j < n, k <= d, as constants [n][d + 1] (k_eval_wide_dot, k_triplegen_wg)
+template <class H = HFr>
 static ShareErrorCode vmat_table(hbmpc_ctx* ctx, size_t n, size_t d, const uint32_t** out) {
     const int impl = ctx->impl;
     return get_table(ctx, key("vmat", {n, d}, impl), [&] {
         std::vector<uint32_t> w;
-        for (const HFr& al : domain_elements<HFr>(n, n)) {
-            HFr p = HFr::one();
+        for (const H& al : domain_elements<H>(n, n)) {
+            H p = H::one();
             for (size_t k = 0; k <= d; ++k) {
                 put_const(w, p, impl);
                 p = p * al;
@@ -1933,10 +1934,12 @@ extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const 
 #include "capi_recover.inc"
 
 // ---- TripleGenNode for all parties on this device (triple_gen/triple_generation.rs:304-364) --------------------------------------
-extern "C" ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, const U256* rt, size_t N,
-                                                      size_t n, size_t t, U256* y_ws, U256* z_ws, U256* opened_out, U256* c_out, uint8_t* status_out,
-                                                      hbmpc_recover_summary* summary_first_dev, hbmpc_recover_summary* summary_dev, void* stream) {
-    REQ_FR(ctx);
+// T: U256 (H = HFr) or uint64_t (H = HGl)
+template <class H, class T>
+static ShareErrorCode triplegen_parties_any(hbmpc_ctx* ctx, const T* a, const T* b, const T* r2t, const T* rt, size_t N, size_t n, size_t t, T* y_ws,
+                                            T* z_ws, T* opened_out, T* c_out, uint8_t* status_out, hbmpc_recover_summary* summary_first_dev,
+                                            hbmpc_recover_summary* summary_dev, void* stream) {
+    constexpr bool gold = std::is_same<T, uint64_t>::value;
     if (!a || !b || !r2t || !rt || !y_ws || !z_ws || !opened_out || !c_out) return fail(ctx, InvalidInput, "null buffer");
     const size_t M = 2 * t + 1, d = 2 * t;
     if (N == 0 || n == 0 || n > 255 || N % M != 0) return fail(ctx, InvalidInput, "N must be a positive multiple of 2t + 1; n in 1 .. 255");
@@ -1946,21 +1949,23 @@ extern "C" ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256
     for (size_t i = 0; i < n; ++i) ids[i] = i;
     // Small batches: one launch, a workgroup per chunk (kernels_triplegen_wg.hpp).  n = 3t + 1 <= 16: every recipient decodes from
     // exactly d + t + 1 senders (no OEC round), and the (party, recipient) pairs fit the workgroup.
-    if (G <= ctx->fused_triplegen_max && n == 3 * t + 1 && n <= 16 && ctx->impl == IMPL_U29 && !ctx->force_generic && ctx->direct_fail) {
+    // (over Goldilocks the four launches are flat at ~28 us and overtake at ~600 chunks: half the threshold)
+    if (G <= (gold ? ctx->fused_triplegen_max / 2 : ctx->fused_triplegen_max) && n == 3 * t + 1 && n <= 16 && (gold || ctx->impl == IMPL_U29) &&
+        !ctx->force_generic && ctx->direct_fail) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         hipStream_t s = pick(ctx, stream);
         const int impl = ctx->impl;
         TripleGenWgArgs ta;
         memset(&ta, 0, sizeof ta);
-        const std::shared_ptr<const DomainInv<HFr>> dom = domain_inv<HFr>(ctx, n);
+        const std::shared_ptr<const DomainInv<H>> dom = domain_inv<H>(ctx, n);
         ShareErrorCode rc = get_table(ctx, ids_key("rec", ids, n, n, d, t, impl), [&] {
-            RecoverTables T = build_recover_tables<HFr>(*dom, ids, d, t, impl);
-            std::vector<uint32_t> both = T.vm;
-            both.insert(both.end(), T.bc.begin(), T.bc.end());
+            RecoverTables T2 = build_recover_tables<H>(*dom, ids, d, t, impl);
+            std::vector<uint32_t> both = T2.vm;
+            both.insert(both.end(), T2.bc.begin(), T2.bc.end());
             return both;
         }, &ta.tab);
         if (rc != ShareSuccess) return rc;
-        rc = vmat_table(ctx, n, d, &ta.vmat);
+        rc = vmat_table<H>(ctx, n, d, &ta.vmat);
         if (rc != ShareSuccess) return rc;
         const ElemConsts cs = elem_consts(impl);
         memcpy(ta.r2, cs.r2, sizeof ta.r2);
@@ -1977,21 +1982,46 @@ extern "C" ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256
         ta.summary = summary_dev ? (uint32_t*)summary_dev : ta.counters + 4;
         if (dirty) HIP_TRY(ctx, hipMemsetAsync(ta.counters, 0, 128, s));
         set_scratch_dirty(ctx, s, true);
-        launch_triplegen_wg(ta, s);
+        launch_triplegen_wg(impl, ta, s);
         HIP_TRY(ctx, hipGetLastError());
         set_scratch_dirty(ctx, s, false);  // the kernel's last workgroup leaves the counters at zero
         return ShareSuccess;
     }
-    // [ab - r]_2t Vandermonde-encoded in chunks of 2t + 1 for every recipient (batch_recon.rs:157-165), all parties in one launch
-    ShareErrorCode rc = hbmpc_dev_triple_encode_parties(ctx, a, b, r2t, G, n, d, n, c_out, y_ws, stream);
-    if (rc != ShareSuccess) return rc;
-    // EvalBatch arm for ALL recipients in one call: the row of sender p for "chunk" j G + g is y_ws + p (n G) + (j G + g)
-    rc = hbmpc_dev_batch_recover_strided(ctx, ids.data(), n, y_ws, n * G, n * G, n, d, t, 1, z_ws, nullptr, status_out, summary_first_dev, stream);
-    if (rc != ShareSuccess) return rc;
-    // RevealBatch arm: everyone interpolates the 2t + 1 opened values per chunk from the n broadcast values
-    rc = hbmpc_dev_batch_recover(ctx, ids.data(), n, z_ws, G, n, d, t, opened_out, nullptr, status_out, summary_dev, stream);
-    if (rc != ShareSuccess) return rc;
-    return hbmpc_dev_triple_finalize_parties(ctx, rt, opened_out, N, n, c_out, stream);  // [c]_t = rt_i + opened (triple_generation.rs:196-208)
+    // [ab - r]_2t Vandermonde-encoded in chunks of 2t + 1 for every recipient (batch_recon.rs:157-165), all parties in one launch;
+    // EvalBatch arm for ALL recipients in one call: the row of sender p for "chunk" j G + g is y_ws + p (n G) + (j G + g);
+    // RevealBatch arm: everyone interpolates the 2t + 1 opened values per chunk from the n broadcast values;
+    // [c]_t = rt_i + opened (triple_generation.rs:196-208)
+    ShareErrorCode rc;
+    if constexpr (gold) {
+        rc = hbmpc_gl_dev_triple_encode_parties(ctx, a, b, r2t, G, n, d, n, c_out, y_ws, stream);
+        if (rc != ShareSuccess) return rc;
+        rc = hbmpc_gl_dev_batch_recover_strided(ctx, ids.data(), n, y_ws, n * G, n * G, n, d, t, 1, z_ws, nullptr, status_out, summary_first_dev, stream);
+        if (rc != ShareSuccess) return rc;
+        rc = hbmpc_gl_dev_batch_recover(ctx, ids.data(), n, z_ws, G, n, d, t, opened_out, nullptr, status_out, summary_dev, stream);
+        if (rc != ShareSuccess) return rc;
+        return hbmpc_gl_dev_triple_finalize_parties(ctx, rt, opened_out, N, n, c_out, stream);
+    } else {
+        rc = hbmpc_dev_triple_encode_parties(ctx, a, b, r2t, G, n, d, n, c_out, y_ws, stream);
+        if (rc != ShareSuccess) return rc;
+        rc = hbmpc_dev_batch_recover_strided(ctx, ids.data(), n, y_ws, n * G, n * G, n, d, t, 1, z_ws, nullptr, status_out, summary_first_dev, stream);
+        if (rc != ShareSuccess) return rc;
+        rc = hbmpc_dev_batch_recover(ctx, ids.data(), n, z_ws, G, n, d, t, opened_out, nullptr, status_out, summary_dev, stream);
+        if (rc != ShareSuccess) return rc;
+        return hbmpc_dev_triple_finalize_parties(ctx, rt, opened_out, N, n, c_out, stream);
+    }
+}
+extern "C" ShareErrorCode hbmpc_dev_triplegen_parties(hbmpc_ctx* ctx, const U256* a, const U256* b, const U256* r2t, const U256* rt, size_t N,
+                                                      size_t n, size_t t, U256* y_ws, U256* z_ws, U256* opened_out, U256* c_out, uint8_t* status_out,
+                                                      hbmpc_recover_summary* summary_first_dev, hbmpc_recover_summary* summary_dev, void* stream) {
+    REQ_FR(ctx);
+    return triplegen_parties_any<HFr>(ctx, a, b, r2t, rt, N, n, t, y_ws, z_ws, opened_out, c_out, status_out, summary_first_dev, summary_dev, stream);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_triplegen_parties(hbmpc_ctx* ctx, const uint64_t* a, const uint64_t* b, const uint64_t* r2t, const uint64_t* rt,
+                                                         size_t N, size_t n, size_t t, uint64_t* y_ws, uint64_t* z_ws, uint64_t* opened_out,
+                                                         uint64_t* c_out, uint8_t* status_out, hbmpc_recover_summary* summary_first_dev,
+                                                         hbmpc_recover_summary* summary_dev, void* stream) {
+    REQ_GL(ctx);
+    return triplegen_parties_any<HGl>(ctx, a, b, r2t, rt, N, n, t, y_ws, z_ws, opened_out, c_out, status_out, summary_first_dev, summary_dev, stream);
 }
 
 // ---- FPMulNode for all parties on this device (fpmul/fpmul.rs:61-110) ----------------------------------------------------------

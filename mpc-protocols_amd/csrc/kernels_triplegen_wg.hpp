@@ -6,7 +6,7 @@
 // SIMD behind a memory round trip (profiles/r04_small_batch_fpmul.txt).  With all parties on one device a chunk of 2t + 1 triples
 // depends on nothing outside it, so one workgroup of 256 lanes takes it from the shares to [c]: a lane per (party, triple) for the
 // local products, a lane per (party, recipient) for the encode, a lane pair per (recipient, table row) and a lane quad per table row
-// for the two decodes (dot_shared).  Covers n = 3t + 1 <= 16 (every recipient then decodes from exactly d + t + 1 = n senders: no
+// for the two decodes (dot_shared; over Goldilocks a lane per row: its products are a few instructions).  Covers n = 3t + 1 <= 16 (every recipient then decodes from exactly d + t + 1 = n senders: no
 // OEC round, a failed chunk is final -- what the separate decodes do in one launch each).
 //
 // Every buffer a caller can see gets the bytes of the separate launches (tests/test_gpu_pipelines.py).
@@ -28,51 +28,68 @@ struct TripleGenWgArgs {
     uint32_t r2[9];                    // R^2: canonical -> Montgomery
 };
 
-// LDS words: X[n][M] | Y[n][n] | Z[n] | opened[M] (limbs, 12-word stride) | bad flags [n + 1] | vmat | tab
+// LDS words: X[n][M] | Y[n][n] | Z[n] | opened[M] (elements in limb form, `ls` words apart) | bad flags [n + 1] | vmat | tab
+// (nl words per constant: 9 and ls = 12 for U29, 2 and 2 for Goldilocks)
 struct TripleGenWgLds {
     int X, Y, Z, O, flags, vmat, tab, total;
-    __host__ __device__ TripleGenWgLds(int n, int t) {
+    __host__ __device__ TripleGenWgLds(int n, int t, int ls, int nl) {
         const int M = 2 * t + 1;
-        X = 0, Y = X + n * M * 12, Z = Y + n * n * 12, O = Z + n * 12, flags = O + M * 12;
+        X = 0, Y = X + n * M * ls, Z = Y + n * n * ls, O = Z + n * ls, flags = O + M * ls;
         vmat = flags + ((n + 1 + 3) & ~3);
-        tab = vmat + n * M * 9;
-        total = tab + (t + M) * M * 9;
+        tab = vmat + n * M * nl;
+        total = tab + (t + M) * M * nl;
     }
 };
 
 template <class F>
 __global__ __launch_bounds__(256) void k_triplegen_wg(TripleGenWgArgs a) {
     using E = typename F::E;
-    static_assert(F::EW == 8 && F::NL == 9, "U29 only");
+    constexpr bool SHARE = F::NL == 9;             // U29: a row's products shared by adjacent lanes (dot_shared); Goldilocks' are cheap
+    constexpr int NL = F::NL, EW = F::EW, LS = SHARE ? 12 : F::NL;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int tid = threadIdx.x, n = a.n, t = a.t, M = 2 * t + 1, nv = t;
     const size_t g = blockIdx.x;
-    const TripleGenWgLds L(n, t);
+    const TripleGenWgLds L(n, t, LS, NL);
     uint32_t *X = lds + L.X, *Yl = lds + L.Y, *Zl = lds + L.Z, *Ol = lds + L.O, *flags = lds + L.flags, *vmat = lds + L.vmat, *tab = lds + L.tab;
     auto put_limbs = [&](uint32_t* dst, const E& v) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) dst[i] = v.l[i];
+        for (int i = 0; i < NL; ++i) dst[i] = v.l[i];
     };
-    auto put_words = [&](uint32_t* dst, const E& canon) {
-        uint32_t w[8];
-        F::to_words(canon, w);
-        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4*>(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+    auto put_words = [&](uint32_t* dst, const E& canon) {  // canonical value -> the stored form
+        if constexpr (SHARE) {
+            uint32_t w[8];
+            F::to_words(canon, w);
+            *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(dst + 4) = make_uint4(w[4], w[5], w[6], w[7]);
+        } else {
+            F::store_lt2r(dst, canon);
+        }
     };
+    auto dot = [&](auto&& value_of, const uint32_t* row, int lk, int sidx) -> E {
+        if constexpr (SHARE) {
+            return dot_shared<F>(value_of, row, M, lk, sidx);
+        } else {
+            typename F::Acc acc;
+            F::acc_zero(acc);
+            for (int i = 0; i < M; ++i) F::acc_mac(acc, value_of(i), row + i * NL);
+            return F::acc_reduce(acc);
+        }
+    };
+    constexpr int LK1 = SHARE ? 1 : 0;
 
     // ---- loads: a lane per (party, triple of the chunk); the tables by everyone ----------------------------------------------------
     const int pk_p = tid / M, pk_k = tid - pk_p * M;
     const bool pk = tid < n * M;
     const size_t e = pk ? (size_t)pk_p * a.N + g * M + pk_k : 0;
     E va = F::zero(), vb = F::zero(), vr = F::zero(), vrt = F::zero();
-    if (pk) va = F::load(a.a + e * 8), vb = F::load(a.b + e * 8), vr = F::load(a.r2t + e * 8), vrt = F::load(a.rt + e * 8);
-    for (int w = tid; w < n * M * 9; w += 256) vmat[w] = a.vmat[w];
-    for (int w = tid; w < (nv + M) * M * 9; w += 256) tab[w] = a.tab[w];
+    if (pk) va = F::load(a.a + e * EW), vb = F::load(a.b + e * EW), vr = F::load(a.r2t + e * EW), vrt = F::load(a.rt + e * EW);
+    for (int w = tid; w < n * M * NL; w += 256) vmat[w] = a.vmat[w];
+    for (int w = tid; w < (nv + M) * M * NL; w += 256) tab[w] = a.tab[w];
     if (tid <= n) flags[tid] = 0;
     // [ab - r]_2t = a_i b_i - r2t_i  (triple_generation.rs:333-340), canonical as k_triple_local stores it
     if (pk) {
         const E am = F::mulc(va, a.r2);
-        put_limbs(X + (pk_p * M + pk_k) * 12, F::canon_loose(F::template sub<2>(F::mont(vb, am), vr)));
+        put_limbs(X + (pk_p * M + pk_k) * LS, F::canon_loose(F::template sub<2>(F::mont(vb, am), vr)));
     }
     __syncthreads();
 
@@ -80,9 +97,9 @@ __global__ __launch_bounds__(256) void k_triplegen_wg(TripleGenWgArgs a) {
     {
         const int p = tid / n, j = tid - p * n;
         if (tid < n * n) {
-            const E y = F::canon_loose(dot_shared<F>([&](int k) { return F::load_const(X + (p * M + k) * 12); }, vmat + (size_t)j * M * 9, M, 0, 0));
-            put_limbs(Yl + (p * n + j) * 12, y);
-            put_words(a.Y + (((size_t)p * n + j) * a.G + g) * 8, y);
+            const E y = F::canon_loose(dot([&](int k) { return F::load_const(X + (p * M + k) * LS); }, vmat + (size_t)j * M * NL, 0, 0));
+            put_limbs(Yl + (p * n + j) * LS, y);
+            put_words(a.Y + (((size_t)p * n + j) * a.G + g) * EW, y);
         }
     }
     __syncthreads();
@@ -90,18 +107,18 @@ __global__ __launch_bounds__(256) void k_triplegen_wg(TripleGenWgArgs a) {
     // ---- the EvalBatch arm (:384-391): recipient j opens its value from the n senders' y_p[j]: t verify rows and the P(0) row, a lane
     // pair per (recipient, row) ----------------------------------------------------------------------------------------------------
     {
-        const int q = tid >> 1, sidx = tid & 1, j = q / (nv + 1), r = q - j * (nv + 1);
+        const int q = tid >> LK1, sidx = tid & ((1 << LK1) - 1), j = q / (nv + 1), r = q - j * (nv + 1);
         E kept = F::zero();
         if (q < n * (nv + 1)) {
-            kept = dot_shared<F>([&](int i) { return F::load_const(Yl + (i * n + j) * 12); }, tab + (size_t)(r < nv ? r : nv) * M * 9, M, 1, sidx);
-            if (r < nv && sidx == 0 && !F::eq_canon(F::canon_loose(kept), F::load_const(Yl + ((M + r) * n + j) * 12))) flags[j] = 1;
+            kept = dot([&](int i) { return F::load_const(Yl + (i * n + j) * LS); }, tab + (size_t)(r < nv ? r : nv) * M * NL, LK1, sidx);
+            if (r < nv && sidx == 0 && !F::eq_canon(F::canon_loose(kept), F::load_const(Yl + ((M + r) * n + j) * LS))) flags[j] = 1;
         }
         __syncthreads();
         if (q < n * (nv + 1) && r == nv && sidx == 0) {
             const bool ok = flags[j] == 0;
             const E z = ok ? F::canon_loose(kept) : F::zero();
-            put_limbs(Zl + j * 12, z);
-            put_words(a.Z + ((size_t)j * a.G + g) * 8, z);
+            put_limbs(Zl + j * LS, z);
+            put_words(a.Z + ((size_t)j * a.G + g) * EW, z);
             if (a.status && j > 0) a.status[(size_t)j * a.G + g] = ok ? 0 : (uint8_t)DecodingError;  // recipient 0's is rewritten by the second decode
             if (!ok) {
                 atomicAdd(a.counters + 24, 1u);
@@ -114,19 +131,19 @@ __global__ __launch_bounds__(256) void k_triplegen_wg(TripleGenWgArgs a) {
     // ---- the RevealBatch arm (:457-467): everyone interpolates the 2t + 1 opened values from the n broadcast z_j: t verify rows and
     // 2t + 1 coefficient rows, a lane quad per row -----------------------------------------------------------------------------------
     {
-        const int lk = M >= 4 ? 2 : 1;
+        const int lk = !SHARE ? 0 : M >= 4 ? 2 : 1;
         const int r = tid >> lk, sidx = tid & ((1 << lk) - 1);
         E kept = F::zero();
         if (r < nv + M) {
-            kept = dot_shared<F>([&](int i) { return F::load_const(Zl + i * 12); }, tab + (size_t)r * M * 9, M, lk, sidx);
-            if (r < nv && sidx == 0 && !F::eq_canon(F::canon_loose(kept), F::load_const(Zl + (M + r) * 12))) flags[n] = 1;
+            kept = dot([&](int i) { return F::load_const(Zl + i * LS); }, tab + (size_t)r * M * NL, lk, sidx);
+            if (r < nv && sidx == 0 && !F::eq_canon(F::canon_loose(kept), F::load_const(Zl + (M + r) * LS))) flags[n] = 1;
         }
         __syncthreads();
         const bool ok = flags[n] == 0;
         if (r >= nv && r < nv + M && sidx == 0) {
             const E o = ok ? F::canon_loose(kept) : F::zero();
-            put_limbs(Ol + (r - nv) * 12, o);
-            put_words(a.opened + (g * M + (r - nv)) * 8, o);
+            put_limbs(Ol + (r - nv) * LS, o);
+            put_words(a.opened + (g * M + (r - nv)) * EW, o);
         }
         if (tid == 0) {
             if (a.status) a.status[g] = ok ? 0 : (uint8_t)DecodingError;
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(256) void k_triplegen_wg(TripleGenWgArgs a) {
     __syncthreads();
 
     // ---- [c]_t = rt_i + opened  (triple_generation.rs:196-208) ------------------------------------------------------------------------
-    if (pk) F::store_loose(a.c + e * 8, F::add(vrt, F::load_const(Ol + pk_k * 12)));
+    if (pk) F::store_loose(a.c + e * EW, F::add(vrt, F::load_const(Ol + pk_k * LS)));
 
     // ---- the summaries: the last workgroup turns the counters into them and leaves the counters at zero ------------------------------
     __syncthreads();

@@ -92,7 +92,7 @@ void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondA
 // FPMulNode for all parties of a small batch in one launch (kernels_fpmul_wave.hpp); false: the shape does not fit a workgroup's LDS
 struct FpmulWaveArgs;
 struct TripleGenWgArgs;
-void launch_triplegen_wg(const TripleGenWgArgs& a, hipStream_t s);  // TripleGenNode, a workgroup per chunk (kernels_triplegen_wg.hpp)
+void launch_triplegen_wg(int impl, const TripleGenWgArgs& a, hipStream_t s);  // TripleGenNode, a workgroup per chunk (kernels_triplegen_wg.hpp): U29 or Goldilocks
 bool launch_fpmul_wave(const FpmulWaveArgs& a, int device, hipStream_t s, bool dry_run);
 // flagged chunks: two cheap interpolation candidates before the OEC/Gao kernel (k_second_chance)
 void launch_second_chance(int impl, const SecondArgs& a, unsigned grid, hipStream_t s);

@@ -345,6 +345,55 @@ def test_small_field_triple_gen_pipeline(eng, n, t, groups):
     assert rc == 0 and [int(v) for v in p0] == [x * y % P for x, y in zip(a, b)]
 
 
+@pytest.mark.parametrize("n,t,groups,tamper", [(4, 1, 7, False), (7, 2, 30, True), (10, 3, 21, False), (13, 4, 9, True), (16, 5, 120, True)])
+def test_small_field_triple_gen_one_launch_equals_four(eng, n, t, groups, tamper):
+    """hbmpc_gl_dev_triplegen_parties as ONE launch (a workgroup per chunk, csrc/kernels_triplegen_wg.hpp over Goldilocks) against
+    the four separate launches (hbmpc_set_fused_triplegen(ctx, 0)): both arms' messages, the opened values, the output shares,
+    statuses and summaries byte for byte, honest or with replaced shares."""
+    import ctypes as C
+    pkg = load_package()
+    N = groups * (2 * t + 1)
+    rng = np.random.default_rng(77 * n + t)
+
+    def share_all(secrets, d):  # [n][N] degree-d sharings by the library's own compute_shares (checked against the oracle elsewhere)
+        co = rng.integers(0, P, (N, d + 1), dtype=np.uint64)
+        co[:, 0] = secrets
+        rc, out = eng.compute_shares(co, n, d)
+        assert rc == 0
+        return out
+
+    a, b, r = (rng.integers(0, P, N, dtype=np.uint64) for _ in range(3))
+    ins = [share_all(a, t), share_all(b, t), share_all(r, 2 * t), share_all(r, t)]
+    if tamper:
+        ins[0][1, 3] = ins[0][2, 3]
+        ins[2][0, N - 1] = ins[2][1, N - 1]
+    res = {}
+    try:
+        for form, fused in (("one", 1 << 20), ("four", 0)):
+            assert eng.L.hbmpc_set_fused_triplegen(eng.ctx, C.c_size_t(fused)) == 0
+            tg = pkg.pipelines.TripleGen(eng, n, t, N)
+            tg.upload(*ins)
+            tg.run(check=False)
+            got = {"c": tg.download_c().copy(), "Y": tg.download_named("Y", (n, n, groups)).copy(), "Z": tg.download_named("Z", (n, groups)).copy(),
+                   "opened": tg.download_named("opened", (N,)).copy()}
+            for nm, arr in (("status", np.zeros(n * groups, dtype=np.uint8)), ("summary", np.zeros(4, dtype=np.uint32)), ("summary_first", np.zeros(4, dtype=np.uint32))):
+                eng.d2h(arr, tg.buffer(nm)[0])
+                got[nm] = arr
+            eng.sync()
+            res[form] = got
+            tg.close()
+    finally:
+        eng.L.hbmpc_set_fused_triplegen(eng.ctx, C.c_size_t(1024))
+    for nm in res["four"]:
+        assert np.array_equal(res["one"][nm], res["four"][nm]), nm
+    if tamper:
+        assert res["one"]["summary_first"][0] > 0
+    else:
+        assert res["one"]["summary"].tolist() == [0, 0, 0xffffffff, 0]
+        opened = [(int(x) * int(y) - int(z)) % P for x, y, z in zip(a, b, r)]
+        assert [int(v) for v in res["one"]["opened"]] == opened
+
+
 def test_in_place_wire_path_small_field(_eng):
     """ark's Vec<Fp64> payloads (u64-LE length + 8-byte LE elements) written by the encode kernel and decoded where
     they arrived; a sender with a non-canonical element is dropped, another one lies in one chunk."""
