@@ -230,6 +230,14 @@ struct Producer : hbmpc_pipe {
     size_t n, t, K;
     Producer(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : hbmpc_pipe(cx, s), n(n_), t(t_), K(K_) {}
     void deal_one(const unsigned char* coeffs, size_t deg, unsigned char* S) {
+        // compute_shares of every dealer's K polynomials: coeffs [dealer][K][deg + 1] -> S [dealer][recipient][K] is the party-batched
+        // encode's layout, so a small batch (the wave-per-chunk kernels: one launch whatever the number of dealers) takes one call
+        // instead of n launches of a few microseconds each; large batches keep a launch per dealer (each fills the chip)
+        if (n * K <= 2048) {
+            PL(f.gl ? hbmpc_gl_dev_vandermonde_apply_parties(ctx, (const uint64_t*)coeffs, K, n, deg, n, (uint64_t*)S, stream)
+                    : hbmpc_dev_vandermonde_apply_parties(ctx, (const U256*)coeffs, K, n, deg, n, (U256*)S, stream));
+            return;
+        }
         for (size_t p = 0; p < n; ++p)  // dealer p: compute_shares of its K polynomials
             PL(f.compute_shares(ctx, coeffs + p * K * (deg + 1) * f.eb, K, n, deg, S + p * n * K * f.eb, stream));
     }
