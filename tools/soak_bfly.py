@@ -43,6 +43,7 @@ for seed in range(first, last):
     xr[:, :G] = T(x.transpose(1, 0, 2))
     tmp = torch.empty((G, d + 1, 4), dtype=torch.int64, device=dev)
     yd = torch.zeros((n, G, 4), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # the library's stream does not wait for torch's (the fills above must have landed)
     assert eng.dev_vandermonde_apply_rows(xr.data_ptr(), stride, G, n, d, tmp.data_ptr(), yd.data_ptr()) == 0
     eng.sync()
     assert np.array_equal(H(yd), ys[1]), ("rows", seed, n, d, G)
@@ -60,6 +61,7 @@ for seed in range(first, last):
         for mode in (1, 0):
             eng.set_matrix_cores(mode, 1)
             c = torch.zeros((G, nn, 4), dtype=torch.int64, device=dev); dg = torch.zeros((G,), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
             assert eng.dev_batch_interpolate(ids, ev.data_ptr(), G, G, nn, c.data_ptr(), dg.data_ptr()) == 0
             eng.sync(); res.append((H(c), dg.cpu().numpy()))
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), ("interpolate", seed, nn, dd, G)
@@ -81,6 +83,7 @@ for seed in range(first, last):
                 eng.set_matrix_cores(mode, 65536)
                 y = torch.zeros((P, nt, Gt, 4), dtype=torch.int64, device=dev)
                 tw = torch.empty((Nt, 4), dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
                 assert eng.dev_triple_encode_parties(ad.data_ptr(), bd.data_ptr(), rd.data_ptr(), Gt, nt, d2, P, tw.data_ptr(), y.data_ptr()) == 0, eng.last_error()
                 eng.sync(); outs.append(y)
             assert torch.equal(outs[0], outs[1]), ("triple", seed, nt, tt, Gt, P)
