@@ -305,6 +305,13 @@ ShareErrorCode hbmpc_dev_batch_recover_strided(hbmpc_ctx* ctx, const size_t* sen
                                                size_t d, size_t t, int p0_only, U256* out_dev,
                                                uint32_t* ncoeffs_out_dev, uint8_t* status_out_dev,
                                                hbmpc_recover_summary* summary_dev, void* stream);
+/* A P(0)-shaped decode that keeps coefficient k of every chunk's polynomial instead of coefficient 0 (k = 0 is P(0)): out_dev[G].
+ * For callers that need one coefficient only -- RanSha's verifiers test the exact degree, i.e. the top coefficient
+ * (share_gen.rs:516-530): a sixth of the rows and of the output of the full decode at t = 5.  Only for calls WITHOUT OEC rounds
+ * (S == d + t + 1, what the handler passes: it fires when that many have arrived, share_gen.rs:497); InvalidInput otherwise. */
+ShareErrorCode hbmpc_dev_batch_recover_coeff_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals_dev, size_t row_stride,
+                                                     size_t G, size_t n, size_t d, size_t t, size_t k, U256* out_dev, uint8_t* status_out_dev,
+                                                     hbmpc_recover_summary* summary_dev, void* stream);
 
 /* ==== a6: RobustShare::recover_secret (one polynomial) ======================================
  * replaces robust_interpolate.rs:94-157 (+ robust_interpolate_fnt :206-266, oec_decode :579-628,
@@ -362,6 +369,22 @@ ShareErrorCode hbmpc_dev_transpose(hbmpc_ctx* ctx, const void* src_dev, size_t r
                                    size_t dst_row_stride, size_t batch, size_t src_batch_stride, size_t dst_batch_stride, void* stream);
 ShareErrorCode hbmpc_dev_check_degree(hbmpc_ctx* ctx, const void* coeffs_dev, const uint8_t* status_dev, size_t G, size_t m,
                                       size_t want_degree, uint32_t* bad_dev, void* stream);
+/* The exact-degree verdict from the top coefficient alone: top_dev[G] = coefficient want_degree of each polynomial (what
+ * hbmpc_dev_batch_recover_coeff_strided writes with k = want_degree), status_dev as above.  A polynomial of at most want_degree + 1
+ * coefficients has that degree iff the coefficient is not zero (want_degree = 0: only the status counts).  Same bad[] as check_degree. */
+ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, const uint8_t* status_dev, size_t G, size_t want_degree,
+                                         uint32_t* bad_dev, void* stream);
+/* RanSha's verifier in one call (share_gen.rs:516-530): recover_secret of G columns from S senders' shares (rows row_stride elements
+ * apart, degree t, threshold t) and the exact-degree test, the verdict accumulated in bad_dev as check_degree does.  ws_dev: G (t + 1)
+ * elements of workspace.  With exactly 2t + 1 senders (no OEC round) and hbmpc_set_producer_fusion on, the decode keeps the top
+ * coefficient only (hbmpc_dev_batch_recover_coeff_strided + hbmpc_dev_check_top_coeff); otherwise the full decode and
+ * hbmpc_dev_check_degree.  Same verdict either way. */
+ShareErrorCode hbmpc_dev_recover_check_degree_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals_dev, size_t row_stride,
+                                                      size_t G, size_t n, size_t t, U256* ws_dev, uint8_t* status_out_dev,
+                                                      hbmpc_recover_summary* summary_dev, uint32_t* bad_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_recover_check_degree_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals_dev,
+                                                         size_t row_stride, size_t G, size_t n, size_t t, uint64_t* ws_dev, uint8_t* status_out_dev,
+                                                         hbmpc_recover_summary* summary_dev, uint32_t* bad_dev, void* stream);
 ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const void* coeffs_t_dev, const void* coeffs_2t_dev, size_t G, size_t m,
                                             size_t t, uint32_t* bad_dev, void* stream);
 
@@ -632,6 +655,9 @@ ShareErrorCode hbmpc_gl_dev_batch_recover_strided(hbmpc_ctx* ctx, const size_t* 
                                                   const uint64_t* evals_dev, size_t row_stride, size_t G, size_t n, size_t d,
                                                   size_t t, int p0_only, uint64_t* out_dev, uint32_t* ncoeffs_out_dev,
                                                   uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_batch_recover_coeff_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals_dev,
+                                                        size_t row_stride, size_t G, size_t n, size_t d, size_t t, size_t k, uint64_t* out_dev,
+                                                        uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, void* stream);
 ShareErrorCode hbmpc_gl_batch_interpolate(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals, size_t G,
                                           size_t n, uint64_t* coeffs_out, uint32_t* degree_out);
 ShareErrorCode hbmpc_gl_dev_batch_interpolate_c0(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals_dev, size_t row_stride,

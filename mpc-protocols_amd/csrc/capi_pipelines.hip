@@ -288,10 +288,11 @@ struct RanSha : Producer {
         // rows 2t .. n - 1 of every batch element are the output, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
         mix(S, x, y, 2 * t, n - 2 * t, split.empty() ? std::vector<Slice>{{out, nout, 0, K}} : split);
         clear_bad();
-        for (size_t i = 0; i < 2 * t; ++i) {  // verifier i: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530)
-            PL(f.recover_strided(ctx, ids.data(), ids.size(), y + i * n * K * f.eb, K, K, n, t, t, 0, poly, nullptr, status, summ, stream));
-            PL(hbmpc_dev_check_degree(ctx, poly, status, K, t + 1, t, bad, stream));
-        }
+        for (size_t i = 0; i < 2 * t; ++i)  // verifier i: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530)
+            PL(f.gl ? hbmpc_gl_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const uint64_t*)(y + i * n * K * f.eb), K, K, n, t,
+                                                                (uint64_t*)poly, status, summ, bad, stream)
+                    : hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)(y + i * n * K * f.eb), K, K, n, t, (U256*)poly,
+                                                             status, summ, bad, stream));
     }
 };
 

@@ -1910,6 +1910,16 @@ extern "C" ShareErrorCode hbmpc_dev_check_degree(hbmpc_ctx* ctx, const void* coe
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, const uint8_t* status_dev, size_t G, size_t want_degree,
+                                                    uint32_t* bad_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!bad_dev || (G && !top_dev) || want_degree > 65535) return fail(ctx, InvalidInput, "null buffer or bad degree");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (G) launch_check_top_coeff(is_gold(ctx) ? 1 : 4, (const uint64_t*)top_dev, status_dev, G, (int)want_degree, bad_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const void* coeffs_t_dev, const void* coeffs_2t_dev, size_t G, size_t m,
                                                        size_t t, uint32_t* bad_dev, void* stream) {
     if (!ctx) return InvalidInput;

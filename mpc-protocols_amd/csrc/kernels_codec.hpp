@@ -207,6 +207,25 @@ __global__ __launch_bounds__(256) void k_check_degree(const uint64_t* __restrict
         atomicMin(bad + 1, (uint32_t)g);
     }
 }
+// The same verdict from the TOP coefficient alone (hbmpc_dev_batch_recover_coeff_strided with k = want): a polynomial of at most
+// `want` coefficients + 1 has degree exactly `want` > 0 iff that coefficient is not zero; want = 0 leaves the status test
+template <int W>
+__global__ __launch_bounds__(256) void k_check_top_coeff(const uint64_t* __restrict__ top, const uint8_t* __restrict__ status, size_t G, int want,
+                                                         uint32_t* __restrict__ bad) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool wrong = false;
+    if (g < G) {
+        uint64_t any = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) any |= top[g * W + w];
+        wrong = (status && status[g] > 1) || (want > 0 && any == 0);
+    }
+    const unsigned long long mask = __ballot(wrong);
+    if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
+        atomicAdd(bad, (uint32_t)__popcll(mask));
+        atomicMin(bad + 1, (uint32_t)g);
+    }
+}
 // RanDouSha verifier (ran_dou_sha/mod.rs:586-589): degree(poly_t) == t, degree(poly_2t) == 2 t and equal constant terms
 template <int W>
 __global__ __launch_bounds__(256) void k_check_double(const uint64_t* __restrict__ ct, const uint64_t* __restrict__ c2t, size_t G, int m, int t,

@@ -125,6 +125,7 @@ void launch_mfma_table(const uint64_t* coeff, int m, int rows, const uint64_t e[
 void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, size_t src_row_stride, uint64_t* dst, size_t dst_row_stride,
                       size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s);
 void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status, size_t G, int m, int want, uint32_t* bad, hipStream_t s);
+void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s);
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s);
 void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,
                             uint32_t* bad, hipStream_t s);

@@ -49,6 +49,11 @@ void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status
     if (ew64 == 4) hipLaunchKernelGGL(k_check_degree<4>, grid, dim3(256), 0, s, coeffs, status, G, m, want, bad);
     else hipLaunchKernelGGL(k_check_degree<1>, grid, dim3(256), 0, s, coeffs, status, G, m, want, bad);
 }
+void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_top_coeff<4>, grid, dim3(256), 0, s, top, status, G, want, bad);
+    else hipLaunchKernelGGL(k_check_top_coeff<1>, grid, dim3(256), 0, s, top, status, G, want, bad);
+}
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s) {
     const dim3 grid((unsigned)((G + 255) / 256));
     if (ew64 == 4) hipLaunchKernelGGL(k_check_double<4>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);

@@ -447,6 +447,13 @@ class Engine:
                                                       C.c_int(1 if p0 else 0), C.c_void_p(out_d), C.c_void_p(nco_d),
                                                       C.c_void_p(status_d), C.c_void_p(summary_d), C.c_void_p(stream))
 
+    def dev_batch_recover_coeff_strided(self, sender_ids, evals_d, row_stride, G, n, d, t, k, out_d, status_d=0, summary_d=0, stream=0):
+        """a P(0)-shaped decode that keeps coefficient k (exactly d + t + 1 senders)"""
+        ids = _sz(sender_ids)
+        return self._f("dev_batch_recover_coeff_strided")(self.ctx, _p(ids), C.c_size_t(len(sender_ids)), C.c_void_p(evals_d), C.c_size_t(row_stride),
+                                                            C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(t), C.c_size_t(k),
+                                                            C.c_void_p(out_d), C.c_void_p(status_d), C.c_void_p(summary_d), C.c_void_p(stream))
+
     def dev_batch_recover_slots(self, sender_ids, row_slots, evals_d, row_stride, G, n, d, t, out_d, p0=False, nco_d=0,
                                 status_d=0, summary_d=0, stream=0):
         return self._f("dev_batch_recover_slots")(self.ctx, _p(_sz(sender_ids)), _p(_sz(row_slots)),

@@ -108,6 +108,44 @@ def test_one_launch_equals_oracle_and_two_launches(family, n, d, t, G, p0):
         e.close()
 
 
+@pytest.mark.parametrize("family,n,d,t,G", [c for c in CASES if c[3] > 0])
+def test_single_coefficient_decode(family, n, d, t, G):
+    """hbmpc_dev_batch_recover_coeff_strided: the P(0)-shaped decode that keeps coefficient k instead of coefficient 0 (RanSha's
+    verifiers need the top one) against column k of the oracle's full decode, for every k and every kernel family; chunks that
+    fail the verification give zero and count; with OEC rounds available (more than d + t + 1 senders) the call is refused."""
+    e = load_package().Engine(0)
+    try:
+        if family == "generic":
+            e.set_force_generic(True)
+        if family == "mfma":
+            e.set_small_batch_chunks(0)
+            e.set_matrix_cores(True, 1)
+        else:
+            e.set_matrix_cores(False)
+        bad = sorted({g for g in (0, 1, 63, 64, G // 2, G - 1) if g < G})
+        ids, ev = make(2000 + n + d, G, n, d, t, bad)
+        rc0, co0, nc0, st0 = O.batch_recover(ids, ev, n, d, t)
+        dev_ev, dev_out, dev_st, dev_su = e.dev_alloc(ev.nbytes), e.dev_alloc(G * 32), e.dev_alloc(G), e.dev_alloc(64)
+        e.h2d(dev_ev, ev)
+        for k in sorted({0, 1, d // 2, d - 1, d}):
+            e.h2d(dev_out, np.full(G * 4, 0xEEEEEEEEEEEEEEEE, dtype=np.uint64))
+            assert e.dev_batch_recover_coeff_strided(ids, dev_ev, G, G, n, d, t, k, dev_out, dev_st, dev_su) == 0, e.last_error()
+            out, st, su = np.zeros((G, 4), dtype=np.uint64), np.zeros(G, dtype=np.uint8), np.zeros(4, dtype=np.uint32)
+            e.d2h(out, dev_out), e.d2h(st, dev_st), e.d2h(su, dev_su)
+            e.sync()
+            assert np.array_equal(st, st0), k
+            assert np.array_equal(out, co0[:, k]), k
+            assert list(su) == [len(bad), len(bad), bad[0], DECODING_ERROR], (k, list(su))
+        assert e.dev_batch_recover_coeff_strided(ids, dev_ev, G, G, n, d, t, d + 1, dev_out, dev_st, dev_su) == 4          # k > d
+        if len(ids) < n:
+            more = [i for i in range(n) if i not in ids][:1] + ids
+            assert e.dev_batch_recover_coeff_strided(more, dev_ev, G, G, n, d, t, d, dev_out, dev_st, dev_su) == 4        # an OEC round exists
+        for p in (dev_ev, dev_out, dev_st, dev_su):
+            e.dev_free(p)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("G", [5000, 50000])   # workgroup per tile / wave per tile on the matrix cores
 def test_every_chunk_fails(G):
     """the failure path is as parallel as the decode: a batch in which EVERY chunk fails"""
