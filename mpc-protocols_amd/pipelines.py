@@ -107,7 +107,8 @@ class _Pipe:
 class TripleGen(_Pipe):
     """n parties, threshold t, N triples (N a multiple of 2t+1).  Buffers a, b, r2t, rt, c are [party][N] canonical.
     Works in either field: the reference runs TripleGenNode over Fr and, in PreprocNodesSmallField
-    (honeybadger/mod.rs:316-324), over GoldilocksField -- the element size follows the engine's field."""
+    (honeybadger/mod.rs:316-324), over GoldilocksField -- the element size follows the engine's field.  run() is one library call
+    (hbmpc_[gl_]dev_triplegen_parties): one launch up to 1 024 chunks of 2t + 1 triples when n = 3t + 1 <= 16, four launches beyond."""
 
     def __init__(self, eng, n, t, N, stream=0, _handle=None):
         self.n, self.t, self.N, self.m, self.G = n, t, N, 2 * t + 1, N // (2 * t + 1)
@@ -126,7 +127,9 @@ class FpMul(_Pipe):
     interpolation, i.e. the RBC path of Multiply::init for < t+1 leftovers that FPMulNode always takes) followed by TruncPr
     with k-bit values and m fractional bits.  open_senders: how many parties' shares an open interpolates from.  Default
     2t+1: the reference opens as soon as that many have arrived (multiplication.rs:388,617, truncpr.rs:202) -- with d = t
-    that is exactly d + t + 1, a decode with no OEC round, which the library runs as one launch.  n = every party's share."""
+    that is exactly d + t + 1, a decode with no OEC round, which the library runs as one launch.  n = every party's share.
+    run() is one library call (hbmpc_dev_fpmul_parties): ONE launch up to 2 048 elements, five launches up to 8 192, four beyond
+    (the first open then forms its senders' shares itself); summary_first / summary hold the two opens' summaries."""
 
     def __init__(self, eng, n, t, N, k, m, stream=0, open_senders=None):
         self.n, self.t, self.N, self.k, self.m = n, t, N, k, m
