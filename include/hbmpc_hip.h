@@ -117,6 +117,10 @@ ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr);
 ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 ShareErrorCode hbmpc_memcpy_d2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+/* `rows` rows of row_bytes bytes each, the rows dst_pitch_bytes / src_pitch_bytes apart (both >= row_bytes): one copy for the same slice of
+ * every party's array */
+ShareErrorCode hbmpc_memcpy_d2d_rows(hbmpc_ctx* ctx, void* dst_dev, size_t dst_pitch_bytes, const void* src_dev, size_t src_pitch_bytes,
+                                     size_t row_bytes, size_t rows, void* stream);
 ShareErrorCode hbmpc_stream_sync(hbmpc_ctx* ctx, void* stream); /* stream == NULL: the ctx's own stream */
 ShareErrorCode hbmpc_stream_create(hbmpc_ctx* ctx, void** stream_out); /* a non-blocking hipStream_t on the ctx's device */
 ShareErrorCode hbmpc_stream_destroy(hbmpc_ctx* ctx, void* stream);

@@ -233,9 +233,15 @@ struct Producer : hbmpc_pipe {
         // compute_shares of every dealer's K polynomials: coeffs [dealer][K][deg + 1] -> S [dealer][recipient][K] is the party-batched
         // encode's layout, so a small batch (the wave-per-chunk kernels: one launch whatever the number of dealers) takes one call
         // instead of n launches of a few microseconds each; large batches keep a launch per dealer (each fills the chip)
-        if (n * K <= 2048) {
-            PL(f.gl ? hbmpc_gl_dev_vandermonde_apply_parties(ctx, (const uint64_t*)coeffs, K, n, deg, n, (uint64_t*)S, stream)
-                    : hbmpc_dev_vandermonde_apply_parties(ctx, (const U256*)coeffs, K, n, deg, n, (U256*)S, stream));
+        if (K <= 1024) {  // as many dealers per call as the wave-per-chunk kernels take in one launch (2048 chunks over all of them)
+            const size_t per = 2048 / K;
+            for (size_t p = 0; p < n; p += per) {
+                const size_t cnt = n - p < per ? n - p : per;
+                const unsigned char* co = coeffs + p * K * (deg + 1) * f.eb;
+                unsigned char* out = S + p * n * K * f.eb;
+                PL(f.gl ? hbmpc_gl_dev_vandermonde_apply_parties(ctx, (const uint64_t*)co, K, n, deg, cnt, (uint64_t*)out, stream)
+                        : hbmpc_dev_vandermonde_apply_parties(ctx, (const U256*)co, K, n, deg, cnt, (U256*)out, stream));
+            }
             return;
         }
         for (size_t p = 0; p < n; ++p)  // dealer p: compute_shares of its K polynomials
@@ -371,13 +377,12 @@ struct Preprocessing : hbmpc_pipe {
         rs->run();
         rd->run();
         if (!in_place) {
+            // the parties' lists, in the reference's order, become TripleGen's [party][N] inputs: one copy per array for all parties
             const size_t eb = f.eb;
-            for (size_t p = 0; p < n; ++p) {  // the parties' lists, in the reference's order, become TripleGen's [party][N] inputs
-                PL(hbmpc_memcpy_d2d(ctx, tg->a + p * N * eb, rs->out + p * rs->nout * eb, N * eb, stream));
-                PL(hbmpc_memcpy_d2d(ctx, tg->b + p * N * eb, rs->out + (p * rs->nout + N) * eb, N * eb, stream));
-                PL(hbmpc_memcpy_d2d(ctx, tg->rt + p * N * eb, rd->out_t + p * rd->nout * eb, N * eb, stream));
-                PL(hbmpc_memcpy_d2d(ctx, tg->r2t + p * N * eb, rd->out_2t + p * rd->nout * eb, N * eb, stream));
-            }
+            PL(hbmpc_memcpy_d2d_rows(ctx, tg->a, N * eb, rs->out, rs->nout * eb, N * eb, n, stream));
+            PL(hbmpc_memcpy_d2d_rows(ctx, tg->b, N * eb, rs->out + N * eb, rs->nout * eb, N * eb, n, stream));
+            PL(hbmpc_memcpy_d2d_rows(ctx, tg->rt, N * eb, rd->out_t, rd->nout * eb, N * eb, n, stream));
+            PL(hbmpc_memcpy_d2d_rows(ctx, tg->r2t, N * eb, rd->out_2t, rd->nout * eb, N * eb, n, stream));
         }
         tg->run();
     }

@@ -463,6 +463,14 @@ extern "C" ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst, const void
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick(ctx, stream)));
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_memcpy_d2d_rows(hbmpc_ctx* ctx, void* dst, size_t dst_pitch_bytes, const void* src, size_t src_pitch_bytes,
+                                                size_t row_bytes, size_t rows, void* stream) {
+    if (!ctx) return InvalidInput;
+    if ((rows && row_bytes && (!dst || !src)) || dst_pitch_bytes < row_bytes || src_pitch_bytes < row_bytes) return fail(ctx, InvalidInput, "null buffer or pitch below the row");
+    if (rows == 0 || row_bytes == 0) return ShareSuccess;
+    HIP_TRY(ctx, hipMemcpy2DAsync(dst, dst_pitch_bytes, src, src_pitch_bytes, row_bytes, rows, hipMemcpyDeviceToDevice, pick(ctx, stream)));
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_memcpy_d2d(hbmpc_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
     if (!ctx) return InvalidInput;
     HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick(ctx, stream)));

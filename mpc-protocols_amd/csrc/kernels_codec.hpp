@@ -136,9 +136,11 @@ __global__ __launch_bounds__(256) void k_validate_canonical(const uint64_t* __re
 // 0 for the zero polynomial
 // (ew64 = 64-bit words per element: 4 for Fr, 1 for Goldilocks)
 __global__ __launch_bounds__(256) void k_poly_degree(const uint64_t* __restrict__ coeffs, size_t G, int m, int ew64,
-                                                     uint32_t* __restrict__ degree_out) {
+                                                     uint32_t* __restrict__ degree_out, uint64_t* __restrict__ c0_out) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G) return;
+    if (c0_out)  // the constant term beside the degree (the RanDouSha verifier keeps these two of an interpolation)
+        for (int w = 0; w < ew64; ++w) c0_out[g * ew64 + w] = coeffs[g * (size_t)m * ew64 + w];
     int deg = 0;
     for (int k = m - 1; k > 0; --k) {
         const uint64_t* c = coeffs + (g * (size_t)m + k) * ew64;

@@ -570,6 +570,7 @@ struct WideArgs {
     int fused;      // a chunk that fails the verification tries the second-chance candidates right here (same wave)
     int tab_words;  // TAB instances: (needed - m + out_width) * m constants, r.vm and r.bc contiguous, staged in LDS
     int lk;         // U29 TAB instances: log2 of the lanes that share a row's products (dot_shared); > 0 only when every row fits the wave
+    int split;      // TAB instances: r.bc does not follow r.vm (a single coefficient row other than row 0): staged word by word from both
 };
 // rows[i], i < 64, from the scalar side: a per-lane index into the argument struct compiles to a VECTOR load from the
 // argument segment -- a full memory round trip in front of the loads that depend on it; sixteen scalar words and a
@@ -603,7 +604,12 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     const uint4* tsrc = reinterpret_cast<const uint4*>(a.vm);
     const int tq = wa.tab_words >> 2;
     uint4 t0 = make_uint4(0, 0, 0, 0);
-    if (TAB && (int)threadIdx.x < tq) t0 = tsrc[threadIdx.x];
+    const int vm_words = nv * M * F::NL;
+    if (TAB && wa.split) {  // one word per thread and pass: the verify rows from r.vm, the output rows from r.bc
+        if ((int)threadIdx.x < wa.tab_words) t0.x = (int)threadIdx.x < vm_words ? a.vm[threadIdx.x] : a.bc[threadIdx.x - vm_words];
+    } else if (TAB && (int)threadIdx.x < tq) {
+        t0 = tsrc[threadIdx.x];
+    }
     {
         uint32_t first[F::EW];
         if (lane < a.needed) {
@@ -611,7 +617,11 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
 #pragma unroll
             for (int w = 0; w < F::EW; ++w) first[w] = src[w];
         }
-        if (TAB && (int)threadIdx.x < tq) reinterpret_cast<uint4*>(tab)[threadIdx.x] = t0;
+        if (TAB && wa.split) {
+            if ((int)threadIdx.x < wa.tab_words) tab[threadIdx.x] = t0.x;
+        } else if (TAB && (int)threadIdx.x < tq) {
+            reinterpret_cast<uint4*>(tab)[threadIdx.x] = t0;
+        }
         if (lane < a.needed) {
 #pragma unroll
             for (int w = 0; w < F::EW; ++w) ys[lane * F::EW + w] = first[w];
@@ -623,8 +633,12 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
         }
     }
     if constexpr (TAB) {  // what one pass of the workgroup did not cover (tables beyond 4 KB), and the words past the last 16 bytes
-        for (int q = threadIdx.x + 256; q < tq; q += 256) reinterpret_cast<uint4*>(tab)[q] = tsrc[q];
-        for (int w = (tq << 2) + threadIdx.x; w < wa.tab_words; w += 256) tab[w] = a.vm[w];
+        if (wa.split) {
+            for (int w = threadIdx.x + 256; w < wa.tab_words; w += 256) tab[w] = w < vm_words ? a.vm[w] : a.bc[w - vm_words];
+        } else {
+            for (int q = threadIdx.x + 256; q < tq; q += 256) reinterpret_cast<uint4*>(tab)[q] = tsrc[q];
+            for (int w = (tq << 2) + threadIdx.x; w < wa.tab_words; w += 256) tab[w] = a.vm[w];
+        }
     }
     __syncthreads();
     auto chunk = [&]() __attribute__((always_inline)) {

@@ -118,7 +118,7 @@ void launch_pack_shares(const uint64_t* values, size_t N, uint64_t id, uint64_t 
 void launch_unpack_shares(const uint64_t* payload, size_t N, uint64_t id, uint64_t degree, uint64_t* values,
                           uint32_t* status, hipStream_t s);
 void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hipStream_t s);
-void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s);
+void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s, uint64_t* c0_out = nullptr);  // c0_out: the constant terms too
 void launch_mfma_table(const uint64_t* coeff, int m, int rows, const uint64_t e[4], uint32_t bmag, uint8_t* table, uint64_t* partial,
                        hipStream_t s);  // kernels_tables.hpp
 // layout + verdict kernels of the preprocessing producers (kernels_codec.hpp); ew64 = 64-bit words per element

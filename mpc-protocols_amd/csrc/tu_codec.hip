@@ -25,9 +25,9 @@ void launch_validate_canonical(const uint64_t* a, size_t N, uint32_t* status, hi
     hipLaunchKernelGGL(k_validate_canonical, dim3((unsigned)((N + 255) / 256 ? (N + 255) / 256 : 1)), dim3(256), 0, s, a, N,
                        status);
 }
-void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s) {
+void launch_poly_degree(const uint64_t* coeffs, size_t G, int m, int ew64, uint32_t* degree_out, hipStream_t s, uint64_t* c0_out) {
     hipLaunchKernelGGL(k_poly_degree, dim3((unsigned)((G + 255) / 256 ? (G + 255) / 256 : 1)), dim3(256), 0, s, coeffs, G, m,
-                       ew64, degree_out);
+                       ew64, degree_out, c0_out);
 }
 void launch_fvec_prefix(uint64_t* payloads, size_t payload_stride_words, size_t G, size_t n_rows, hipStream_t s) {
     hipLaunchKernelGGL(k_fvec_prefix, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, s, payloads, payload_stride_words, G, n_rows);

@@ -36,12 +36,15 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
 }
 // LDS of one workgroup of k_batch_recover_wide; *tab_words = 0 when the call's table cannot be staged (not contiguous, or
 // beyond what a launch may ask for without raising the function's limit)
-static size_t wide_lds(int impl, const RecoverArgs& ra, bool p0, int* tab_words) {
+static size_t wide_lds(int impl, const RecoverArgs& ra, bool p0, int* tab_words, int* split) {
     const size_t ew = impl == 2 ? 2 : 8, nl = impl == 0 ? 9 : impl == 1 ? 8 : 2;
     const size_t nv = (size_t)(ra.needed - ra.m), ow = p0 ? 1 : (size_t)ra.m;
     const size_t front = 4 * (size_t)ra.needed * ew * 4;
     const size_t tw = (nv + ow) * (size_t)ra.m * nl;
-    const bool staged = ra.bc == ra.vm + nv * (size_t)ra.m * nl && ((uintptr_t)ra.vm & 15) == 0 && front + tw * 4 <= 64 * 1024;
+    const bool fits = front + tw * 4 <= 64 * 1024;
+    const bool contiguous = ra.bc == ra.vm + nv * (size_t)ra.m * nl && ((uintptr_t)ra.vm & 15) == 0;
+    const bool staged = fits && (contiguous || p0);  // a single output row elsewhere in the table (one coefficient): staged from both ranges
+    *split = staged && !contiguous ? 1 : 0;
     *tab_words = staged ? (int)tw : 0;
     return front + (staged ? tw * 4 : 0);
 }
@@ -52,7 +55,7 @@ void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondA
     wa.fused = sc != nullptr;
     if (sc) wa.sc = *sc;
     else memset(&wa.sc, 0, sizeof wa.sc);
-    const size_t lds = wide_lds(impl, ra, p0, &wa.tab_words);
+    const size_t lds = wide_lds(impl, ra, p0, &wa.tab_words, &wa.split);
     const bool tab = wa.tab_words != 0;
     wa.lk = 0;
     if (tab && impl == 0) {  // U29: a row's products shared by up to four lanes while every row still fits the wave (dot_shared)
