@@ -378,6 +378,23 @@ ShareErrorCode hbmpc_dev_check_degree(hbmpc_ctx* ctx, const void* coeffs_dev, co
  * coefficients has that degree iff the coefficient is not zero (want_degree = 0: only the status counts).  Same bad[] as check_degree. */
 ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, const uint8_t* status_dev, size_t G, size_t want_degree,
                                          uint32_t* bad_dev, void* stream);
+/* RanDouSha's verifier (ran_dou_sha/mod.rs:557-602) interpolates a polynomial through ALL n shares and asks three things of it: is its
+ * degree exactly d, and its constant term.  hbmpc_[gl_]dev_interpolate_degree_check_strided answers them without the full interpolation:
+ * the first d + 1 points (in id order) interpolate, every other point is a verify row (the points lie on a polynomial of degree <= d iff
+ * all of them agree), and only coefficients 0 and d are computed: sel_out_dev[G][2] = (constant term, coefficient d), status_out_dev[G] = 0
+ * or DecodingError (the points are on no such polynomial; both coefficients are then zero).  The interpolant of degree < S through the
+ * points has degree exactly d iff status is 0 and coefficient d is not zero.  Over Fr on the wave-per-chunk and matrix-core kernels
+ * (12 + 7 table rows instead of 2 x 16 at n = 16, t = 5); other shapes run the full interpolation into ws_dev [G][S] and pick the same
+ * values from it.  hbmpc_dev_check_double_share_sel: the verdict from two such results (degrees t and 2t, equal constant terms),
+ * accumulated in bad_dev as check_double_share does. */
+ShareErrorCode hbmpc_dev_interpolate_degree_check_strided(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals_dev, size_t row_stride,
+                                                          size_t G, size_t n, size_t d, U256* ws_dev, U256* sel_out_dev, uint8_t* status_out_dev,
+                                                          void* stream);
+ShareErrorCode hbmpc_gl_dev_interpolate_degree_check_strided(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals_dev,
+                                                             size_t row_stride, size_t G, size_t n, size_t d, uint64_t* ws_dev,
+                                                             uint64_t* sel_out_dev, uint8_t* status_out_dev, void* stream);
+ShareErrorCode hbmpc_dev_check_double_share_sel(hbmpc_ctx* ctx, const void* sel_t_dev, const uint8_t* status_t_dev, const void* sel_2t_dev,
+                                                const uint8_t* status_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream);
 /* RanSha's verifier in one call (share_gen.rs:516-530): recover_secret of G columns from S senders' shares (rows row_stride elements
  * apart, degree t, threshold t) and the exact-degree test, the verdict accumulated in bad_dev as check_degree does.  ws_dev: G (t + 1)
  * elements of workspace.  With exactly 2t + 1 senders (no OEC round) and hbmpc_set_producer_fusion on, the decode keeps the top

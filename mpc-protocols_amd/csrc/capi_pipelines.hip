@@ -306,7 +306,7 @@ struct RanSha : Producer {
 // interpolates both polynomials through ALL n shares (ran_dou_sha/mod.rs:557-602)
 struct RanDouSha : Producer {
     size_t nout;
-    unsigned char *coeffs_t, *coeffs_2t, *S_t, *S_2t, *x, *y_t, *y_2t, *poly, *c0_t, *c0_2t, *out_t, *out_2t;
+    unsigned char *coeffs_t, *coeffs_2t, *S_t, *S_2t, *x, *y_t, *y_2t, *poly, *c0_t, *c0_2t, *out_t, *out_2t, *sel_t, *sel_2t, *st_t, *st_2t;
     uint32_t *deg_t, *deg_2t;
     std::vector<size_t> ids;
     std::vector<Slice> split_t, split_2t;
@@ -315,13 +315,15 @@ struct RanDouSha : Producer {
         return (t + 1) * K;
     }
     RanDouSha(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
-        arena((n * K * (3 * t + 2) + 5 * n * n * K + K * n + 2 * K + 2 * n * nout) * f.eb + 8 * K + (1 << 14));
+        arena((n * K * (3 * t + 2) + 5 * n * n * K + K * n + 6 * K + 2 * n * nout) * f.eb + 10 * K + (1 << 14));
         coeffs_t = take("coeffs_t", n * K * (t + 1)), coeffs_2t = take("coeffs_2t", n * K * (2 * t + 1));
         S_t = take("S_t", n * n * K), S_2t = take("S_2t", n * n * K);
         x = take("x", n * n * K), y_t = take("y_t", n * n * K), y_2t = take("y_2t", n * n * K);
         poly = take("poly", K * n);  // workspace of the verifier interpolations that have no c0-only kernel
         c0_t = take("c0_t", K), c0_2t = take("c0_2t", K);
         deg_t = reinterpret_cast<uint32_t*>(take_bytes("deg_t", 4 * K, K)), deg_2t = reinterpret_cast<uint32_t*>(take_bytes("deg_2t", 4 * K, K));
+        sel_t = take("sel_t", 2 * K), sel_2t = take("sel_2t", 2 * K);  // (constant term, top coefficient) of a verifier's two polynomials
+        st_t = take_bytes("st_t", K, K), st_2t = take_bytes("st_2t", K, K);
         bad = reinterpret_cast<uint32_t*>(take_bytes("bad", 64, 16));
         out_t = take("out_t", n * nout), out_2t = take("out_2t", n * nout);  // [party][K][t + 1]  (ran_dou_sha/mod.rs:314-331)
         for (size_t i = 0; i < n; ++i) ids.push_back(i);
@@ -337,6 +339,14 @@ struct RanDouSha : Producer {
         clear_bad();
         for (size_t i = t + 1; i < n; ++i) {  // step 3: verifier i interpolates both sharings through all n shares and tests the
                                               // degrees and the constant terms (:586-602) -- it keeps nothing else of them
+            if (!f.gl && 2 * t < n) {  // the two questions answered without the full interpolation (hbmpc_dev_interpolate_degree_check_strided)
+                PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_t + i * n * K * f.eb), K, K, n, t, (U256*)poly,
+                                                              (U256*)sel_t, st_t, stream));
+                PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_2t + i * n * K * f.eb), K, K, n, 2 * t, (U256*)poly,
+                                                              (U256*)sel_2t, st_2t, stream));
+                PL(hbmpc_dev_check_double_share_sel(ctx, sel_t, st_t, sel_2t, st_2t, K, t, bad, stream));
+                continue;
+            }
             PL(f.interpolate_c0(ctx, ids.data(), n, y_t + i * n * K * f.eb, K, K, n, poly, c0_t, deg_t, stream));
             PL(f.interpolate_c0(ctx, ids.data(), n, y_2t + i * n * K * f.eb, K, K, n, poly, c0_2t, deg_2t, stream));
             PL(hbmpc_dev_check_double_share_c0(ctx, c0_t, deg_t, c0_2t, deg_2t, K, t, bad, stream));

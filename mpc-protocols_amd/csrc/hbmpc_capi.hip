@@ -1928,6 +1928,16 @@ extern "C" ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* 
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_dev_check_double_share_sel(hbmpc_ctx* ctx, const void* sel_t_dev, const uint8_t* status_t_dev, const void* sel_2t_dev,
+                                                           const uint8_t* status_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream) {
+    if (!ctx) return InvalidInput;
+    if (!bad_dev || (G && (!sel_t_dev || !sel_2t_dev || !status_t_dev || !status_2t_dev))) return fail(ctx, InvalidInput, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (G) launch_check_double_sel(is_gold(ctx) ? 1 : 4, (const uint64_t*)sel_t_dev, status_t_dev, (const uint64_t*)sel_2t_dev, status_2t_dev, G, (int)t, bad_dev, s);
+    HIP_TRY(ctx, hipGetLastError());
+    return ShareSuccess;
+}
 extern "C" ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const void* coeffs_t_dev, const void* coeffs_2t_dev, size_t G, size_t m,
                                                        size_t t, uint32_t* bad_dev, void* stream) {
     if (!ctx) return InvalidInput;

@@ -228,6 +228,43 @@ __global__ __launch_bounds__(256) void k_check_top_coeff(const uint64_t* __restr
         atomicMin(bad + 1, (uint32_t)g);
     }
 }
+// RanDouSha's verifier from the two kept coefficients of each interpolation (hbmpc_dev_interpolate_degree_check_strided): sel_t / sel_2t are
+// [G][2] = (constant term, coefficient t resp. 2t); a status above 1 says the points did not lie on a polynomial of that degree at all
+template <int W>
+__global__ __launch_bounds__(256) void k_check_double_sel(const uint64_t* __restrict__ sel_t, const uint8_t* __restrict__ st_t,
+                                                          const uint64_t* __restrict__ sel_2t, const uint8_t* __restrict__ st_2t, size_t G, int t,
+                                                          uint32_t* __restrict__ bad) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool wrong = false;
+    if (g < G) {
+        const uint64_t *a = sel_t + g * 2 * W, *b = sel_2t + g * 2 * W;
+        uint64_t top_a = 0, top_b = 0, diff = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) top_a |= a[W + w], top_b |= b[W + w], diff |= a[w] ^ b[w];
+        wrong = st_t[g] > 1 || st_2t[g] > 1 || (t > 0 && (top_a == 0 || top_b == 0)) || diff != 0;
+    }
+    const unsigned long long mask = __ballot(wrong);
+    if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
+        atomicAdd(bad, (uint32_t)__popcll(mask));
+        atomicMin(bad + 1, (uint32_t)g);
+    }
+}
+// the same two coefficients and the verdict from a FULL interpolation (coeffs [G][m]): the form of the shapes the selective decode
+// does not cover
+template <int W>
+__global__ __launch_bounds__(256) void k_pick_two(const uint64_t* __restrict__ coeffs, size_t G, int m, int d, uint64_t* __restrict__ sel,
+                                                  uint8_t* __restrict__ status) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    const uint64_t* c = coeffs + g * (size_t)m * W;
+    uint64_t high = 0;
+    for (int k = d + 1; k < m; ++k)
+#pragma unroll
+        for (int w = 0; w < W; ++w) high |= c[(size_t)k * W + w];
+    status[g] = high ? (uint8_t)8 : 0;  // ShareErrorCode::DecodingError
+#pragma unroll
+    for (int w = 0; w < W; ++w) sel[g * 2 * W + w] = high ? 0 : c[w], sel[g * 2 * W + W + w] = high ? 0 : c[(size_t)d * W + w];
+}
 // RanDouSha verifier (ran_dou_sha/mod.rs:586-589): degree(poly_t) == t, degree(poly_2t) == 2 t and equal constant terms
 template <int W>
 __global__ __launch_bounds__(256) void k_check_double(const uint64_t* __restrict__ ct, const uint64_t* __restrict__ c2t, size_t G, int m, int t,

@@ -571,6 +571,7 @@ struct WideArgs {
     int tab_words;  // TAB instances: (needed - m + out_width) * m constants, r.vm and r.bc contiguous, staged in LDS
     int lk;         // U29 TAB instances: log2 of the lanes that share a row's products (dot_shared); > 0 only when every row fits the wave
     int split;      // TAB instances: r.bc does not follow r.vm (a single coefficient row other than row 0): staged word by word from both
+    int ow;         // !P0_ONLY instances: output rows per chunk when not all m (a table of selected coefficient rows); 0 = m
 };
 // rows[i], i < 64, from the scalar side: a per-lane index into the argument struct compiles to a VECTOR load from the
 // argument segment -- a full memory round trip in front of the loads that depend on it; sixteen scalar words and a
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     const size_t g_raw = (size_t)blockIdx.x * 4 + wave;
     const bool live = g_raw < a.G;
     const size_t g = live ? g_raw : a.G - 1;
-    const int M = a.m, nv = a.needed - M, ow = P0_ONLY ? 1 : M;
+    const int M = a.m, nv = a.needed - M, ow = P0_ONLY ? 1 : wa.ow ? wa.ow : M;
     uint32_t* ys = tile + (size_t)wave * a.needed * F::EW;
     uint32_t* tab = tile + (size_t)4 * a.needed * F::EW;
     // --- every global load first ---

@@ -88,7 +88,7 @@ bool launch_mfma_bfly_d(int m, const mf::MfmaRowsArgs& a, int device, hipStream_
 // small batches: one wave per chunk, one evaluation point / one table row per lane (k_eval_wide, k_batch_recover_wide)
 void launch_eval_wide(int impl, const uint32_t* x, size_t G, int n, int dp1, const uint32_t* alpha, EvalOut y, hipStream_t s);
 void launch_eval_wide_dot(const uint32_t* x, size_t G, int n, int dp1, const uint32_t* vmat, EvalOut y, hipStream_t s);  // U29, vmat [n][dp1] <= 48 KB
-void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s);
+void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* fused_second, hipStream_t s, int ow_sel = 0);  // ow_sel: output rows when the table holds selected ones
 // FPMulNode for all parties of a small batch in one launch (kernels_fpmul_wave.hpp); false: the shape does not fit a workgroup's LDS
 struct FpmulWaveArgs;
 struct TripleGenWgArgs;
@@ -125,6 +125,9 @@ void launch_mfma_table(const uint64_t* coeff, int m, int rows, const uint64_t e[
 void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, size_t src_row_stride, uint64_t* dst, size_t dst_row_stride,
                       size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s);
 void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status, size_t G, int m, int want, uint32_t* bad, hipStream_t s);
+void launch_check_double_sel(int ew64, const uint64_t* sel_t, const uint8_t* st_t, const uint64_t* sel_2t, const uint8_t* st_2t, size_t G, int t, uint32_t* bad,
+                             hipStream_t s);
+void launch_pick_two(int ew64, const uint64_t* coeffs, size_t G, int m, int d, uint64_t* sel, uint8_t* status, hipStream_t s);
 void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s);
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s);
 void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,

@@ -54,6 +54,17 @@ void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status
     if (ew64 == 4) hipLaunchKernelGGL(k_check_top_coeff<4>, grid, dim3(256), 0, s, top, status, G, want, bad);
     else hipLaunchKernelGGL(k_check_top_coeff<1>, grid, dim3(256), 0, s, top, status, G, want, bad);
 }
+void launch_check_double_sel(int ew64, const uint64_t* sel_t, const uint8_t* st_t, const uint64_t* sel_2t, const uint8_t* st_2t, size_t G, int t, uint32_t* bad,
+                             hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_double_sel<4>, grid, dim3(256), 0, s, sel_t, st_t, sel_2t, st_2t, G, t, bad);
+    else hipLaunchKernelGGL(k_check_double_sel<1>, grid, dim3(256), 0, s, sel_t, st_t, sel_2t, st_2t, G, t, bad);
+}
+void launch_pick_two(int ew64, const uint64_t* coeffs, size_t G, int m, int d, uint64_t* sel, uint8_t* status, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256));
+    if (ew64 == 4) hipLaunchKernelGGL(k_pick_two<4>, grid, dim3(256), 0, s, coeffs, G, m, d, sel, status);
+    else hipLaunchKernelGGL(k_pick_two<1>, grid, dim3(256), 0, s, coeffs, G, m, d, sel, status);
+}
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s) {
     const dim3 grid((unsigned)((G + 255) / 256));
     if (ew64 == 4) hipLaunchKernelGGL(k_check_double<4>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);

@@ -36,9 +36,9 @@ void launch_recover_generic(int impl, bool p0, const RecoverArgs& ra, unsigned g
 }
 // LDS of one workgroup of k_batch_recover_wide; *tab_words = 0 when the call's table cannot be staged (not contiguous, or
 // beyond what a launch may ask for without raising the function's limit)
-static size_t wide_lds(int impl, const RecoverArgs& ra, bool p0, int* tab_words, int* split) {
+static size_t wide_lds(int impl, const RecoverArgs& ra, bool p0, int ow_sel, int* tab_words, int* split) {
     const size_t ew = impl == 2 ? 2 : 8, nl = impl == 0 ? 9 : impl == 1 ? 8 : 2;
-    const size_t nv = (size_t)(ra.needed - ra.m), ow = p0 ? 1 : (size_t)ra.m;
+    const size_t nv = (size_t)(ra.needed - ra.m), ow = p0 ? 1 : ow_sel ? (size_t)ow_sel : (size_t)ra.m;
     const size_t front = 4 * (size_t)ra.needed * ew * 4;
     const size_t tw = (nv + ow) * (size_t)ra.m * nl;
     const bool fits = front + tw * 4 <= 64 * 1024;
@@ -48,18 +48,19 @@ static size_t wide_lds(int impl, const RecoverArgs& ra, bool p0, int* tab_words,
     *tab_words = staged ? (int)tw : 0;
     return front + (staged ? tw * 4 : 0);
 }
-void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* sc, hipStream_t s) {
+void launch_recover_wide(int impl, bool p0, const RecoverArgs& ra, const SecondArgs* sc, hipStream_t s, int ow_sel) {
     const unsigned grid = (unsigned)((ra.G + 3) / 4);
     WideArgs wa;
     wa.r = ra;
     wa.fused = sc != nullptr;
     if (sc) wa.sc = *sc;
     else memset(&wa.sc, 0, sizeof wa.sc);
-    const size_t lds = wide_lds(impl, ra, p0, &wa.tab_words, &wa.split);
+    wa.ow = p0 ? 0 : ow_sel;
+    const size_t lds = wide_lds(impl, ra, p0, ow_sel, &wa.tab_words, &wa.split);
     const bool tab = wa.tab_words != 0;
     wa.lk = 0;
     if (tab && impl == 0) {  // U29: a row's products shared by up to four lanes while every row still fits the wave (dot_shared)
-        const int rows = (ra.needed - ra.m) + (p0 ? 1 : ra.m);
+        const int rows = (ra.needed - ra.m) + (p0 ? 1 : ow_sel ? ow_sel : ra.m);
         while (wa.lk < 2 && (rows << (wa.lk + 1)) <= 64 && (2 << wa.lk) <= ra.m) ++wa.lk;
     }
 #define HBMPC_WIDE(F, P0) \

@@ -146,6 +146,51 @@ def test_single_coefficient_decode(family, n, d, t, G):
         e.close()
 
 
+@pytest.mark.parametrize("n,d,G", [(16, 5, 300), (16, 10, 300), (16, 5, 20000), (16, 10, 20000), (7, 2, 1000), (13, 8, 70001), (4, 1, 64), (31, 10, 9000),
+                                   (20, 17, 500), (20, 17, 9000)])
+@pytest.mark.parametrize("fusion", [1, 0])
+def test_interpolate_degree_check(n, d, G, fusion):
+    """hbmpc_dev_interpolate_degree_check_strided (RanDouSha's verifier: the degree and the constant term of the polynomial through ALL
+    n shares, ran_dou_sha/mod.rs:557-602) against the oracle's full interpolation: points of a degree-d polynomial give status 0 and
+    (c_0, c_d); a polynomial of lower degree gives c_d = 0; one point moved off gives DecodingError and zeros -- on the wave-per-chunk
+    and matrix-core kernels (the selective decode) and, with hbmpc_set_producer_fusion(0), through the full interpolation."""
+    e = load_package().Engine(0)
+    try:
+        assert e.L.hbmpc_set_producer_fusion(e.ctx, C.c_int(fusion)) == 0
+        x = rnd(4000 + n + d, G, d + 1)
+        low, off = [1, G // 3], [0, 2, G // 2, G - 1]
+        for g in low:
+            x[g, d] = 0                                              # degree below d
+        rc, y = O.vandermonde_apply(x, n, d)
+        assert rc == 0
+        ids = list(range(n))
+        ids = ids[1::2] + ids[0::2]                                   # an arrival order that is not sorted
+        ev = np.ascontiguousarray(y[ids])
+        for k, g in enumerate(off):
+            ev[(d + 1 + k) % n if d + 1 < n else 0, g, 0] ^= np.uint64(1 + k)
+        if d + 1 == n:
+            off = []                                                  # every set of n points lies on a polynomial of degree <= n - 1
+            ev = np.ascontiguousarray(y[ids])
+        dev_ev, dev_ws, dev_sel, dev_st = e.dev_alloc(ev.nbytes), e.dev_alloc(G * n * 32), e.dev_alloc(G * 64), e.dev_alloc(G)
+        e.h2d(dev_ev, ev)
+        e.h2d(dev_sel, np.full(G * 8, 0xEEEEEEEEEEEEEEEE, dtype=np.uint64))
+        assert e.dev_interpolate_degree_check_strided(ids, dev_ev, G, G, n, d, dev_ws, dev_sel, dev_st) == 0, e.last_error()
+        sel, st = np.zeros((G, 2, 4), dtype=np.uint64), np.zeros(G, dtype=np.uint8)
+        e.d2h(sel, dev_sel), e.d2h(st, dev_st)
+        e.sync()
+        want_st = np.zeros(G, dtype=np.uint8)
+        want_st[off] = DECODING_ERROR
+        assert np.array_equal(st, want_st)
+        want = np.stack([x[:, 0], x[:, d]], axis=1)
+        want[off] = 0
+        assert np.array_equal(sel, want)
+        assert not sel[low, 1].any()
+        for p in (dev_ev, dev_ws, dev_sel, dev_st):
+            e.dev_free(p)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("G", [5000, 50000])   # workgroup per tile / wave per tile on the matrix cores
 def test_every_chunk_fails(G):
     """the failure path is as parallel as the decode: a batch in which EVERY chunk fails"""
