@@ -386,26 +386,33 @@ ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, co
  * points has degree exactly d iff status is 0 and coefficient d is not zero.  Over Fr on the wave-per-chunk and matrix-core kernels
  * (12 + 7 table rows instead of 2 x 16 at n = 16, t = 5); other shapes run the full interpolation into ws_dev [G][S] and pick the same
  * values from it.  hbmpc_dev_check_double_share_sel: the verdict from two such results (degrees t and 2t, equal constant terms),
- * accumulated in bad_dev as check_double_share does. */
+ * accumulated in bad_dev as check_double_share does.
+ * groups > 1 (interpolate_degree_check) / columns > 0 (check_double_share_sel: G = groups x columns entries): several verifiers in one call,
+ * verifier q's sender rows q * group_stride elements after verifier 0's and its results at sel_out_dev + q G 2, status_out_dev + q G; bad[1] is
+ * the lowest failing column.  ONE launch while groups * G chunks fit the wave-per-chunk decode, a loop otherwise. */
 ShareErrorCode hbmpc_dev_interpolate_degree_check_strided(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals_dev, size_t row_stride,
-                                                          size_t G, size_t n, size_t d, U256* ws_dev, U256* sel_out_dev, uint8_t* status_out_dev,
-                                                          void* stream);
+                                                          size_t G, size_t n, size_t d, size_t groups, size_t group_stride, U256* ws_dev,
+                                                          U256* sel_out_dev, uint8_t* status_out_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_interpolate_degree_check_strided(hbmpc_ctx* ctx, const size_t* ids, size_t S, const uint64_t* evals_dev,
-                                                             size_t row_stride, size_t G, size_t n, size_t d, uint64_t* ws_dev,
-                                                             uint64_t* sel_out_dev, uint8_t* status_out_dev, void* stream);
+                                                             size_t row_stride, size_t G, size_t n, size_t d, size_t groups, size_t group_stride,
+                                                             uint64_t* ws_dev, uint64_t* sel_out_dev, uint8_t* status_out_dev, void* stream);
 ShareErrorCode hbmpc_dev_check_double_share_sel(hbmpc_ctx* ctx, const void* sel_t_dev, const uint8_t* status_t_dev, const void* sel_2t_dev,
-                                                const uint8_t* status_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream);
+                                                const uint8_t* status_2t_dev, size_t G, size_t columns, size_t t, uint32_t* bad_dev, void* stream);
 /* RanSha's verifier in one call (share_gen.rs:516-530): recover_secret of G columns from S senders' shares (rows row_stride elements
  * apart, degree t, threshold t) and the exact-degree test, the verdict accumulated in bad_dev as check_degree does.  ws_dev: G (t + 1)
  * elements of workspace.  With exactly 2t + 1 senders (no OEC round) and hbmpc_set_producer_fusion on, the decode keeps the top
  * coefficient only (hbmpc_dev_batch_recover_coeff_strided + hbmpc_dev_check_top_coeff); otherwise the full decode and
- * hbmpc_dev_check_degree.  Same verdict either way. */
+ * hbmpc_dev_check_degree.  Same verdict either way.
+ * groups > 1: that many verifiers in one call -- verifier q's sender rows start q * group_stride elements after verifier 0's, bad[1] is the
+ * lowest failing column of any of them; ONE launch while groups * G chunks fit the wave-per-chunk decode (no OEC round), a loop otherwise.
+ * ws_dev: max(groups G, G (t + 1)) elements, status_out_dev: groups G bytes. */
 ShareErrorCode hbmpc_dev_recover_check_degree_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals_dev, size_t row_stride,
-                                                      size_t G, size_t n, size_t t, U256* ws_dev, uint8_t* status_out_dev,
-                                                      hbmpc_recover_summary* summary_dev, uint32_t* bad_dev, void* stream);
+                                                      size_t G, size_t n, size_t t, size_t groups, size_t group_stride, U256* ws_dev,
+                                                      uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev, uint32_t* bad_dev, void* stream);
 ShareErrorCode hbmpc_gl_dev_recover_check_degree_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const uint64_t* evals_dev,
-                                                         size_t row_stride, size_t G, size_t n, size_t t, uint64_t* ws_dev, uint8_t* status_out_dev,
-                                                         hbmpc_recover_summary* summary_dev, uint32_t* bad_dev, void* stream);
+                                                         size_t row_stride, size_t G, size_t n, size_t t, size_t groups, size_t group_stride,
+                                                         uint64_t* ws_dev, uint8_t* status_out_dev, hbmpc_recover_summary* summary_dev,
+                                                         uint32_t* bad_dev, void* stream);
 ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const void* coeffs_t_dev, const void* coeffs_2t_dev, size_t G, size_t m,
                                             size_t t, uint32_t* bad_dev, void* stream);
 

@@ -267,6 +267,7 @@ struct RanSha : Producer {
     size_t nout;
     unsigned char *coeffs, *S, *x, *y, *poly, *out;
     uint8_t* status;
+    bool grouped;
     std::vector<size_t> ids;
     std::vector<Slice> split;  // set by Preprocessing: where the output slices go instead of `out`
     static size_t checked_nout(size_t n, size_t t, size_t K) {  // before the arena is sized from n - 2t
@@ -277,13 +278,15 @@ struct RanSha : Producer {
         : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
         if (verify_senders == 0) verify_senders = 2 * t + 1;
         if (verify_senders < 2 * t + 1 || verify_senders > n) throw PipeError{InvalidInput};
-        arena((n * K * (t + 1) + 3 * n * n * K + K * (t + 1) + n * nout) * f.eb + K + (1 << 14));
+        grouped = 2 * t * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: workspace for all of them
+        const size_t poly_el = K * (grouped && 2 * t > t + 1 ? 2 * t : t + 1), status_b = grouped ? 2 * t * K + 1 : K;
+        arena((n * K * (t + 1) + 3 * n * n * K + poly_el + n * nout) * f.eb + status_b + (1 << 14));
         coeffs = take("coeffs", n * K * (t + 1));  // [dealer][K][t + 1]
         S = take("S", n * n * K);                  // [dealer][recipient][K]
         x = take("x", n * n * K);
         y = take("y", n * n * K);                  // [row i][party][K]
-        poly = take("poly", K * (t + 1));
-        status = take_bytes("status", K, K);
+        poly = take("poly", poly_el);
+        status = take_bytes("status", status_b, K);
         summ = reinterpret_cast<hbmpc_recover_summary*>(take_bytes("summary", 64, 16));
         bad = reinterpret_cast<uint32_t*>(take_bytes("bad", 64, 16));
         out = take("out", n * nout);               // [party][K][n - 2t]: the reference's output order (share_gen.rs:199-203)
@@ -294,10 +297,21 @@ struct RanSha : Producer {
         // rows 2t .. n - 1 of every batch element are the output, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
         mix(S, x, y, 2 * t, n - 2 * t, split.empty() ? std::vector<Slice>{{out, nout, 0, K}} : split);
         clear_bad();
-        for (size_t i = 0; i < 2 * t; ++i)  // verifier i: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530)
-            PL(f.gl ? hbmpc_gl_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const uint64_t*)(y + i * n * K * f.eb), K, K, n, t,
+        // verifiers 0 .. 2t - 1: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530); verifier i's sender rows are
+        // y + i n K: all of them in one call (one launch for a small batch: `grouped` sized the workspace for it)
+        const size_t nver = 2 * t;
+        if (nver == 0) return;
+        if (grouped) {
+            PL(f.gl ? hbmpc_gl_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const uint64_t*)y, K, K, n, t, nver, n * K, (uint64_t*)poly,
+                                                                status, summ, bad, stream)
+                    : hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)y, K, K, n, t, nver, n * K, (U256*)poly, status, summ,
+                                                             bad, stream));
+            return;
+        }
+        for (size_t i = 0; i < nver; ++i)
+            PL(f.gl ? hbmpc_gl_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const uint64_t*)(y + i * n * K * f.eb), K, K, n, t, 1, 0,
                                                                 (uint64_t*)poly, status, summ, bad, stream)
-                    : hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)(y + i * n * K * f.eb), K, K, n, t, (U256*)poly,
+                    : hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)(y + i * n * K * f.eb), K, K, n, t, 1, 0, (U256*)poly,
                                                              status, summ, bad, stream));
     }
 };
@@ -308,6 +322,7 @@ struct RanDouSha : Producer {
     size_t nout;
     unsigned char *coeffs_t, *coeffs_2t, *S_t, *S_2t, *x, *y_t, *y_2t, *poly, *c0_t, *c0_2t, *out_t, *out_2t, *sel_t, *sel_2t, *st_t, *st_2t;
     uint32_t *deg_t, *deg_2t;
+    bool grouped;
     std::vector<size_t> ids;
     std::vector<Slice> split_t, split_2t;
     static size_t checked_nout(size_t n, size_t t, size_t K) {
@@ -315,15 +330,17 @@ struct RanDouSha : Producer {
         return (t + 1) * K;
     }
     RanDouSha(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
-        arena((n * K * (3 * t + 2) + 5 * n * n * K + K * n + 6 * K + 2 * n * nout) * f.eb + 10 * K + (1 << 14));
+        grouped = (n - t - 1) * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: room for all their results
+        const size_t vr = grouped ? n - t - 1 : 1;
+        arena((n * K * (3 * t + 2) + 5 * n * n * K + K * n + (2 + 4 * vr) * K + 2 * n * nout) * f.eb + (8 + 2 * vr) * K + (1 << 14));
         coeffs_t = take("coeffs_t", n * K * (t + 1)), coeffs_2t = take("coeffs_2t", n * K * (2 * t + 1));
         S_t = take("S_t", n * n * K), S_2t = take("S_2t", n * n * K);
         x = take("x", n * n * K), y_t = take("y_t", n * n * K), y_2t = take("y_2t", n * n * K);
         poly = take("poly", K * n);  // workspace of the verifier interpolations that have no c0-only kernel
         c0_t = take("c0_t", K), c0_2t = take("c0_2t", K);
         deg_t = reinterpret_cast<uint32_t*>(take_bytes("deg_t", 4 * K, K)), deg_2t = reinterpret_cast<uint32_t*>(take_bytes("deg_2t", 4 * K, K));
-        sel_t = take("sel_t", 2 * K), sel_2t = take("sel_2t", 2 * K);  // (constant term, top coefficient) of a verifier's two polynomials
-        st_t = take_bytes("st_t", K, K), st_2t = take_bytes("st_2t", K, K);
+        sel_t = take("sel_t", 2 * K * vr), sel_2t = take("sel_2t", 2 * K * vr);  // (constant term, top coefficient) of a verifier's two polynomials
+        st_t = take_bytes("st_t", K * vr, K), st_2t = take_bytes("st_2t", K * vr, K);
         bad = reinterpret_cast<uint32_t*>(take_bytes("bad", 64, 16));
         out_t = take("out_t", n * nout), out_2t = take("out_2t", n * nout);  // [party][K][t + 1]  (ran_dou_sha/mod.rs:314-331)
         for (size_t i = 0; i < n; ++i) ids.push_back(i);
@@ -337,14 +354,24 @@ struct RanDouSha : Producer {
         mix(S_t, x, y_t, 0, t + 1, split_t.empty() ? std::vector<Slice>{{out_t, nout, 0, K}} : split_t);
         mix(S_2t, x, y_2t, 0, t + 1, split_2t.empty() ? std::vector<Slice>{{out_2t, nout, 0, K}} : split_2t);
         clear_bad();
-        for (size_t i = t + 1; i < n; ++i) {  // step 3: verifier i interpolates both sharings through all n shares and tests the
-                                              // degrees and the constant terms (:586-602) -- it keeps nothing else of them
-            if (!f.gl && 2 * t < n) {  // the two questions answered without the full interpolation (hbmpc_dev_interpolate_degree_check_strided)
-                PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_t + i * n * K * f.eb), K, K, n, t, (U256*)poly,
+        // step 3: verifiers t + 1 .. n - 1 interpolate both sharings through all n shares and test the degrees and the constant terms
+        // (:586-602) -- they keep nothing else of them
+        const size_t nver = n - t - 1, v0 = (t + 1) * n * K * f.eb;  // verifier i's sender rows: y + i n K
+        if (!f.gl && 2 * t < n && grouped) {  // all verifiers in one call each (hbmpc_dev_interpolate_degree_check_strided)
+            PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_t + v0), K, K, n, t, nver, n * K, (U256*)poly, (U256*)sel_t, st_t,
+                                                          stream));
+            PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_2t + v0), K, K, n, 2 * t, nver, n * K, (U256*)poly, (U256*)sel_2t,
+                                                          st_2t, stream));
+            PL(hbmpc_dev_check_double_share_sel(ctx, sel_t, st_t, sel_2t, st_2t, nver * K, K, t, bad, stream));
+            return;
+        }
+        for (size_t i = t + 1; i < n; ++i) {
+            if (!f.gl && 2 * t < n) {  // the two questions answered without the full interpolation
+                PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_t + i * n * K * f.eb), K, K, n, t, 1, 0, (U256*)poly,
                                                               (U256*)sel_t, st_t, stream));
-                PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_2t + i * n * K * f.eb), K, K, n, 2 * t, (U256*)poly,
+                PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_2t + i * n * K * f.eb), K, K, n, 2 * t, 1, 0, (U256*)poly,
                                                               (U256*)sel_2t, st_2t, stream));
-                PL(hbmpc_dev_check_double_share_sel(ctx, sel_t, st_t, sel_2t, st_2t, K, t, bad, stream));
+                PL(hbmpc_dev_check_double_share_sel(ctx, sel_t, st_t, sel_2t, st_2t, K, 0, t, bad, stream));
                 continue;
             }
             PL(f.interpolate_c0(ctx, ids.data(), n, y_t + i * n * K * f.eb, K, K, n, poly, c0_t, deg_t, stream));

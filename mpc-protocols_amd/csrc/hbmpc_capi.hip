@@ -1918,23 +1918,29 @@ extern "C" ShareErrorCode hbmpc_dev_check_degree(hbmpc_ctx* ctx, const void* coe
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, const uint8_t* status_dev, size_t G, size_t want_degree,
-                                                    uint32_t* bad_dev, void* stream) {
+// columns > 0: the G entries are several verifiers' columns one after the other; bad[1] is the lowest failing COLUMN (g mod columns)
+static ShareErrorCode check_top_coeff_any(hbmpc_ctx* ctx, const void* top_dev, const uint8_t* status_dev, size_t G, size_t want_degree, uint32_t* bad_dev,
+                                          void* stream, size_t columns) {
     if (!ctx) return InvalidInput;
     if (!bad_dev || (G && !top_dev) || want_degree > 65535) return fail(ctx, InvalidInput, "null buffer or bad degree");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
-    if (G) launch_check_top_coeff(is_gold(ctx) ? 1 : 4, (const uint64_t*)top_dev, status_dev, G, (int)want_degree, bad_dev, s);
+    if (G) launch_check_top_coeff(is_gold(ctx) ? 1 : 4, (const uint64_t*)top_dev, status_dev, G, (int)want_degree, bad_dev, s, columns);
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
+extern "C" ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, const uint8_t* status_dev, size_t G, size_t want_degree,
+                                                    uint32_t* bad_dev, void* stream) {
+    return check_top_coeff_any(ctx, top_dev, status_dev, G, want_degree, bad_dev, stream, 0);
+}
 extern "C" ShareErrorCode hbmpc_dev_check_double_share_sel(hbmpc_ctx* ctx, const void* sel_t_dev, const uint8_t* status_t_dev, const void* sel_2t_dev,
-                                                           const uint8_t* status_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream) {
+                                                           const uint8_t* status_2t_dev, size_t G, size_t columns, size_t t, uint32_t* bad_dev, void* stream) {
     if (!ctx) return InvalidInput;
     if (!bad_dev || (G && (!sel_t_dev || !sel_2t_dev || !status_t_dev || !status_2t_dev))) return fail(ctx, InvalidInput, "null buffer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
-    if (G) launch_check_double_sel(is_gold(ctx) ? 1 : 4, (const uint64_t*)sel_t_dev, status_t_dev, (const uint64_t*)sel_2t_dev, status_2t_dev, G, (int)t, bad_dev, s);
+    if (columns && G % columns != 0) return fail(ctx, InvalidInput, "G must be a multiple of the columns");
+    if (G) launch_check_double_sel(is_gold(ctx) ? 1 : 4, (const uint64_t*)sel_t_dev, status_t_dev, (const uint64_t*)sel_2t_dev, status_2t_dev, G, (int)t, bad_dev, s, columns);
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }

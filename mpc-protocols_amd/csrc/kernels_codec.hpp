@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_check_degree(const uint64_t* __restrict
 // `want` coefficients + 1 has degree exactly `want` > 0 iff that coefficient is not zero; want = 0 leaves the status test
 template <int W>
 __global__ __launch_bounds__(256) void k_check_top_coeff(const uint64_t* __restrict__ top, const uint8_t* __restrict__ status, size_t G, int want,
-                                                         uint32_t* __restrict__ bad) {
+                                                         uint32_t* __restrict__ bad, size_t columns) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool wrong = false;
     if (g < G) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_check_top_coeff(const uint64_t* __restr
     const unsigned long long mask = __ballot(wrong);
     if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
         atomicAdd(bad, (uint32_t)__popcll(mask));
-        atomicMin(bad + 1, (uint32_t)g);
+        atomicMin(bad + 1, (uint32_t)(columns ? g % columns : g));  // several verifiers' columns in one launch: the column
     }
 }
 // RanDouSha's verifier from the two kept coefficients of each interpolation (hbmpc_dev_interpolate_degree_check_strided): sel_t / sel_2t are
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_check_top_coeff(const uint64_t* __restr
 template <int W>
 __global__ __launch_bounds__(256) void k_check_double_sel(const uint64_t* __restrict__ sel_t, const uint8_t* __restrict__ st_t,
                                                           const uint64_t* __restrict__ sel_2t, const uint8_t* __restrict__ st_2t, size_t G, int t,
-                                                          uint32_t* __restrict__ bad) {
+                                                          uint32_t* __restrict__ bad, size_t columns) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool wrong = false;
     if (g < G) {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_check_double_sel(const uint64_t* __rest
     const unsigned long long mask = __ballot(wrong);
     if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
         atomicAdd(bad, (uint32_t)__popcll(mask));
-        atomicMin(bad + 1, (uint32_t)g);
+        atomicMin(bad + 1, (uint32_t)(columns ? g % columns : g));
     }
 }
 // the same two coefficients and the verdict from a FULL interpolation (coeffs [G][m]): the form of the shapes the selective decode

@@ -46,6 +46,10 @@ struct RecoverArgs {
                              // leaves it so, k_unscale)
     uint32_t* summary;       // {n_fallback, n_failed, first_failed, first_error}: initialised by block 0 of this kernel
     int direct;              // 1: the call has no OEC round and this kernel is all of it (see fail_chunk / finish_direct)
+    // k_batch_recover_wide only: the G chunks are `group` consecutive ones per GROUP, and group q's values start q * group_stride
+    // elements further on in every sender row (several verifiers' columns in one launch: each verifier has its own block of sender
+    // rows); 0: one dense range
+    size_t group, group_stride;
 };
 // Words that one kernel of a call hands to the next and that are WRITTEN WITH ATOMICS (the flagged-chunk counters,
 // the summary) must be read with an agent-scope atomic load (global_load ... sc1), never with a plain or scalar load:
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     const bool live = g_raw < a.G;
     const size_t g = live ? g_raw : a.G - 1;
     const int M = a.m, nv = a.needed - M, ow = P0_ONLY ? 1 : wa.ow ? wa.ow : M;
+    const size_t gin = a.group ? (g / a.group) * a.group_stride + g % a.group : g;  // where the chunk's values are in a sender row
     uint32_t* ys = tile + (size_t)wave * a.needed * F::EW;
     uint32_t* tab = tile + (size_t)4 * a.needed * F::EW;
     // --- every global load first ---
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
     {
         uint32_t first[F::EW];
         if (lane < a.needed) {
-            const uint32_t* src = a.evals + ((size_t)row_of_lane(a.rows, lane) * a.row_stride + g) * F::EW;
+            const uint32_t* src = a.evals + ((size_t)row_of_lane(a.rows, lane) * a.row_stride + gin) * F::EW;
 #pragma unroll
             for (int w = 0; w < F::EW; ++w) first[w] = src[w];
         }
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
             for (int w = 0; w < F::EW; ++w) ys[lane * F::EW + w] = first[w];
         }
         for (int i = lane + 64; i < a.needed; i += 64) {
-            const uint32_t* src = a.evals + ((size_t)a.rows[i] * a.row_stride + g) * F::EW;
+            const uint32_t* src = a.evals + ((size_t)a.rows[i] * a.row_stride + gin) * F::EW;
 #pragma unroll
             for (int w = 0; w < F::EW; ++w) ys[i * F::EW + w] = src[w];
         }

@@ -126,9 +126,9 @@ void launch_transpose(int ew64, const uint64_t* src, size_t rows, size_t cols, s
                       size_t batch, size_t src_batch_stride, size_t dst_batch_stride, hipStream_t s);
 void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status, size_t G, int m, int want, uint32_t* bad, hipStream_t s);
 void launch_check_double_sel(int ew64, const uint64_t* sel_t, const uint8_t* st_t, const uint64_t* sel_2t, const uint8_t* st_2t, size_t G, int t, uint32_t* bad,
-                             hipStream_t s);
+                             hipStream_t s, size_t columns = 0);
 void launch_pick_two(int ew64, const uint64_t* coeffs, size_t G, int m, int d, uint64_t* sel, uint8_t* status, hipStream_t s);
-void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s);
+void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s, size_t columns = 0);
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s);
 void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,
                             uint32_t* bad, hipStream_t s);

@@ -49,16 +49,16 @@ void launch_check_degree(int ew64, const uint64_t* coeffs, const uint8_t* status
     if (ew64 == 4) hipLaunchKernelGGL(k_check_degree<4>, grid, dim3(256), 0, s, coeffs, status, G, m, want, bad);
     else hipLaunchKernelGGL(k_check_degree<1>, grid, dim3(256), 0, s, coeffs, status, G, m, want, bad);
 }
-void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s) {
+void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status, size_t G, int want, uint32_t* bad, hipStream_t s, size_t columns) {
     const dim3 grid((unsigned)((G + 255) / 256));
-    if (ew64 == 4) hipLaunchKernelGGL(k_check_top_coeff<4>, grid, dim3(256), 0, s, top, status, G, want, bad);
-    else hipLaunchKernelGGL(k_check_top_coeff<1>, grid, dim3(256), 0, s, top, status, G, want, bad);
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_top_coeff<4>, grid, dim3(256), 0, s, top, status, G, want, bad, columns);
+    else hipLaunchKernelGGL(k_check_top_coeff<1>, grid, dim3(256), 0, s, top, status, G, want, bad, columns);
 }
 void launch_check_double_sel(int ew64, const uint64_t* sel_t, const uint8_t* st_t, const uint64_t* sel_2t, const uint8_t* st_2t, size_t G, int t, uint32_t* bad,
-                             hipStream_t s) {
+                             hipStream_t s, size_t columns) {
     const dim3 grid((unsigned)((G + 255) / 256));
-    if (ew64 == 4) hipLaunchKernelGGL(k_check_double_sel<4>, grid, dim3(256), 0, s, sel_t, st_t, sel_2t, st_2t, G, t, bad);
-    else hipLaunchKernelGGL(k_check_double_sel<1>, grid, dim3(256), 0, s, sel_t, st_t, sel_2t, st_2t, G, t, bad);
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_double_sel<4>, grid, dim3(256), 0, s, sel_t, st_t, sel_2t, st_2t, G, t, bad, columns);
+    else hipLaunchKernelGGL(k_check_double_sel<1>, grid, dim3(256), 0, s, sel_t, st_t, sel_2t, st_2t, G, t, bad, columns);
 }
 void launch_pick_two(int ew64, const uint64_t* coeffs, size_t G, int m, int d, uint64_t* sel, uint8_t* status, hipStream_t s) {
     const dim3 grid((unsigned)((G + 255) / 256));

@@ -454,11 +454,11 @@ class Engine:
                                                             C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(t), C.c_size_t(k),
                                                             C.c_void_p(out_d), C.c_void_p(status_d), C.c_void_p(summary_d), C.c_void_p(stream))
 
-    def dev_interpolate_degree_check_strided(self, ids, evals_d, row_stride, G, n, d, ws_d, sel_d, status_d, stream=0):
+    def dev_interpolate_degree_check_strided(self, ids, evals_d, row_stride, G, n, d, ws_d, sel_d, status_d, stream=0, groups=1, group_stride=0):
         """do the len(ids) points of every chunk lie on a polynomial of degree <= d?  sel[G][2] = (constant term, coefficient d), status[G]"""
         return self._f("dev_interpolate_degree_check_strided")(self.ctx, _p(_sz(ids)), C.c_size_t(len(ids)), C.c_void_p(evals_d), C.c_size_t(row_stride),
-                                                                 C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_void_p(ws_d), C.c_void_p(sel_d),
-                                                                 C.c_void_p(status_d), C.c_void_p(stream))
+                                                                 C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_size_t(groups), C.c_size_t(group_stride),
+                                                                 C.c_void_p(ws_d), C.c_void_p(sel_d), C.c_void_p(status_d), C.c_void_p(stream))
 
     def dev_batch_recover_slots(self, sender_ids, row_slots, evals_d, row_stride, G, n, d, t, out_d, p0=False, nco_d=0,
                                 status_d=0, summary_d=0, stream=0):
