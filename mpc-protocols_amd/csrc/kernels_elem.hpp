@@ -86,7 +86,26 @@ __global__ __launch_bounds__(256) void k_triple_finalize(const uint32_t* __restr
                                                          uint32_t* __restrict__ out) {
     HB_GID
     HB_PID
-    F::store_loose(out + ip * F::EW, F::add(F::load(rt + ip * F::EW), F::load(opened + i * F::EW)));
+    if constexpr (F::EW == 8) {
+        // both operands are canonical 256-bit integers: one add with carry and one conditional subtraction of r on the stored words
+        // (no limb conversion: the kernel moves 96 bytes per element and should cost what they cost)
+        const uint4 a0 = *reinterpret_cast<const uint4*>(rt + ip * 8), a1 = *reinterpret_cast<const uint4*>(rt + ip * 8 + 4);
+        const uint4 b0 = *reinterpret_cast<const uint4*>(opened + i * 8), b1 = *reinterpret_cast<const uint4*>(opened + i * 8 + 4);
+        const uint32_t a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        constexpr uint32_t R[8] = {0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u};
+        uint32_t sum[8], dif[8], c = 0, bo = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] = __builtin_addc(a[k], b[k], c, &c);  // < 2 r < 2^256: no carry out
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dif[k] = __builtin_subc(sum[k], R[k], bo, &bo);
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = bo ? sum[k] : dif[k];
+        *reinterpret_cast<uint4*>(out + ip * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(out + ip * 8 + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+    } else {
+        F::store_loose(out + ip * F::EW, F::add(F::load(rt + ip * F::EW), F::load(opened + i * F::EW)));
+    }
 }
 // mul/multiplication.rs:417-426:  d_sh = a - x, e_sh = b - y
 template <class F>
