@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void k_eval_wide(const uint32_t* __restrict__ 
 // The same for U29 as a table product: a wave per chunk, 2^lk lanes per evaluation point j, y_j = sum_k alpha_j^k x_k with the
 // constants alpha_j^k staged in LDS once per workgroup (vmat [n][dp1]) -- depth ceil(dp1 / 2^lk) x 81 + 72 dependent
 // v_mad_u64_u32 instead of Horner's (dp1 - 1) x 153 (n = 16, d = 5, four lanes per point: 234 against 765; a lone wave per SIMD
-// issues one every 16 cycles, profiles/r04_small_batch_fpmul.txt).  dot_shared: kernels_recover.hpp.
+// issues one every ~10 cycles, profiles/r01_isa_rates.txt, r04_small_batch_fpmul.txt).  dot_shared: kernels_recover.hpp.
 template <class F>
 __global__ __launch_bounds__(256) void k_eval_wide_dot(const uint32_t* __restrict__ x, size_t G, int n, int dp1,
                                                        const uint32_t* __restrict__ vmat, uint32_t* __restrict__ y, size_t ys, int lk) {

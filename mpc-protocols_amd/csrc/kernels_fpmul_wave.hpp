@@ -3,7 +3,7 @@
 // At the batch sizes the protocols run a fixed-point multiplication at (a few hundred to a few thousand elements) the five
 // launches of the separate steps -- the shares Multiply opens, their decode, finalize_mul + r' + the share TruncPr opens, its
 // decode, TruncPr's last step -- cost 4 - 13 us each whatever the batch (profiles/r04_small_batch_fpmul.txt): a lone wave
-// per SIMD walks a chain of 16-cycle v_mad_u64_u32 behind a memory round trip, five times over.  With all parties on one
+// per SIMD walks a chain of v_mad_u64_u32 at ~10 cycles each (profiles/r01_isa_rates.txt) behind a memory round trip, five times over.  With all parties on one
 // device every step of an element depends on that element alone, so one wave can take it from the triple to the output
 // shares: one round trip of loads, and the multiplications of a step spread over the lanes the step would leave idle
 // (a lane per table row in the decodes; a lane per (party, product) between them -- every product of a step is the same

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void k_second_chance_m(SecondArgs a) {
 // One table row times the M values of a chunk with the products SHARED by 2^lk adjacent lanes (lk = 0, 1, 2; U29): lane s of
 // them takes the terms i = s, s + 2^lk, ..; the carry-folded partial sums (columns < 2^30) are added across the quad by DPP
 // (quad_perm [1,0,3,2], then [2,3,0,1]) and every lane reduces the total.  Only lane 0's partial sum carries the bias of
-// acc_zero.  A lone wave per SIMD issues a v_mad_u64_u32 every 16 cycles: the 81 m of a row's products are the latency of a
+// acc_zero.  A lone wave per SIMD issues a v_mad_u64_u32 every ~10 cycles (profiles/r01_isa_rates.txt): the 81 m of a row's products are the latency of a
 // small decode, and the lanes that would idle take three quarters of them (profiles/r04_small_batch_fpmul.txt).
 // The lanes that share a row must be active together (whole pairs / quads).
 template <class F, class Y>
@@ -590,7 +590,7 @@ HB_DEV int row_of_lane(const RowsArg& rows, int i) {
 // LDS of one workgroup (4 chunks): [4][needed] sender values | TAB: the verify and output rows' constants, staged once per
 // workgroup: both loads of a chunk -- table and sender values -- are in flight together and the m products of a row run
 // from LDS, instead of m dependent round trips for the constants and a fourth of the table traffic.  (At n = 16 a decode
-// of 1024 chunks takes 13 us either way: a lone wave per SIMD spends them in its ~570 16-cycle v_mad_u64_u32 and one
+// of 1024 chunks takes 13 us either way: a lone wave per SIMD spends them in its ~570 v_mad_u64_u32 at ~10 cycles each and one
 // round trip; profiles/r04_small_batch_fpmul.txt.)
 template <class F, bool P0_ONLY, bool TAB = true>
 __global__ __launch_bounds__(256) void k_batch_recover_wide(WideArgs wa) {
