@@ -98,7 +98,9 @@ typedef struct {
  * same loop never; tools/repro_stale.hip for the isolated effect).  A multi-kernel call (batch_recover: optimistic
  * kernel, then the fallback kernels through status bytes, lists and counters) cannot be made safe against that from
  * inside; the library keeps its own scratch in hipMalloc memory and reads every atomically written hand-off word with
- * agent-scope atomic loads.  Pointer attributes do not distinguish the two kinds, so nothing is rejected. */
+ * agent-scope atomic loads.  Pointer attributes do not distinguish the two kinds (HIP_POINTER_ATTRIBUTE_MEMPOOL_HANDLE is
+ * hipErrorNotSupported on ROCm 7.2), so no buffer is rejected; hbmpc_stream_pool_release_threshold / hbmpc_stream_pool_retain
+ * below report and repair the pool's configuration instead. */
 
 /* ---- context --------------------------------------------------------------------------- */
 /* device: HIP device ordinal (>= 0).  There is no CPU mode. */
@@ -114,6 +116,12 @@ FieldKind hbmpc_field_of(const hbmpc_ctx* ctx); /* the field the context was cre
  * kernel writes and the next reads: see DESIGN.md section 4, "Memory the library hands between kernels". */
 ShareErrorCode hbmpc_dev_alloc(hbmpc_ctx* ctx, size_t bytes, void** dptr_out);
 ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr);
+/* Hosts that hand the library buffers from the stream-ordered pool (hipMallocAsync; see "Device buffers" above): the release threshold
+ * of the CURRENT pool of the context's device -- 0, the platform's default, is the unsafe configuration -- and the one-call remedy, which
+ * makes that pool keep its freed blocks (threshold = UINT64_MAX; hipMemPoolTrimTo still returns memory on request).  Call once, before
+ * the first hipMallocAsync whose buffer reaches an hbmpc_dev_* call; a host with its own pool (hipMemPoolCreate) sets the attribute on it. */
+ShareErrorCode hbmpc_stream_pool_release_threshold(hbmpc_ctx* ctx, uint64_t* threshold_out);
+ShareErrorCode hbmpc_stream_pool_retain(hbmpc_ctx* ctx);
 ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes, void* stream);
 ShareErrorCode hbmpc_memcpy_d2h(hbmpc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, void* stream);
 ShareErrorCode hbmpc_memcpy_d2d(hbmpc_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);

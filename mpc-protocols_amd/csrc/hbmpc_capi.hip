@@ -452,6 +452,24 @@ extern "C" ShareErrorCode hbmpc_dev_free(hbmpc_ctx* ctx, void* dptr) {
     HIP_TRY(ctx, hipFree(dptr));
     return ShareSuccess;
 }
+// The stream-ordered pool of the context's device (hipMallocAsync): caller buffers from it are safe only while the pool retains its
+// freed blocks (include/hbmpc_hip.h, "Device buffers").  Pointer attributes do not say which allocator a buffer came from
+// (HIP_POINTER_ATTRIBUTE_MEMPOOL_HANDLE: hipErrorNotSupported on ROCm 7.2, tools/probe_pool_attr.hip), so the check is on the pool.
+extern "C" ShareErrorCode hbmpc_stream_pool_release_threshold(hbmpc_ctx* ctx, uint64_t* threshold_out) {
+    if (!ctx || !threshold_out) return InvalidInput;
+    hipMemPool_t pool = nullptr;
+    HIP_TRY(ctx, hipDeviceGetMemPool(&pool, ctx->device));
+    HIP_TRY(ctx, hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, threshold_out));
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_stream_pool_retain(hbmpc_ctx* ctx) {
+    if (!ctx) return InvalidInput;
+    hipMemPool_t pool = nullptr;
+    uint64_t keep = ~0ull;
+    HIP_TRY(ctx, hipDeviceGetMemPool(&pool, ctx->device));
+    HIP_TRY(ctx, hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    return ShareSuccess;
+}
 static hipStream_t pick(hbmpc_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 extern "C" ShareErrorCode hbmpc_memcpy_h2d(hbmpc_ctx* ctx, void* dst, const void* src, size_t bytes, void* stream) {
     if (!ctx) return InvalidInput;

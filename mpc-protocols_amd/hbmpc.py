@@ -309,6 +309,20 @@ class Engine:
     def dev_free(self, ptr: int):
         self.L.hbmpc_dev_free(self.ctx, C.c_void_p(ptr))
 
+    def stream_pool_release_threshold(self) -> int:
+        """Release threshold of the device's current stream-ordered pool (0 = the platform default, under which hipMallocAsync
+        buffers are NOT safe to hand to the library: include/hbmpc_hip.h, 'Device buffers')."""
+        v = C.c_uint64(0)
+        rc = self.L.hbmpc_stream_pool_release_threshold(self.ctx, C.byref(v))
+        if rc != 0:
+            raise HbmpcError(f"hbmpc_stream_pool_release_threshold -> {rc}: {self.last_error()}")
+        return v.value
+
+    def stream_pool_retain(self):
+        rc = self.L.hbmpc_stream_pool_retain(self.ctx)
+        if rc != 0:
+            raise HbmpcError(f"hbmpc_stream_pool_retain -> {rc}: {self.last_error()}")
+
     def h2d(self, dptr: int, arr: np.ndarray, stream=0):
         arr = np.ascontiguousarray(arr)
         rc = self.L.hbmpc_memcpy_h2d(self.ctx, C.c_void_p(dptr), _p(arr), C.c_size_t(arr.nbytes), C.c_void_p(stream))

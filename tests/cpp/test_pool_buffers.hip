@@ -78,11 +78,15 @@ int main() {
     // (ROCm 7.2, gfx950: every second episode of this very test; hipMalloc buffers in the same loop never) -- a platform
     // matter no library can repair from inside.  POOL_DEFAULT_THRESHOLD=1 runs the test in that configuration.
     if (!getenv("POOL_DEFAULT_THRESHOLD")) {
-        hipMemPool_t pool;
-        CK(hipDeviceGetDefaultMemPool(&pool, 0));
-        uint64_t thr = ~0ull;
-        CK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr));
-        printf("release threshold of the default pool raised: freed blocks stay in the pool\n");
+        uint64_t before = 1, after = 0;
+        OK(hbmpc_stream_pool_release_threshold(ctx, &before));
+        OK(hbmpc_stream_pool_retain(ctx));
+        OK(hbmpc_stream_pool_release_threshold(ctx, &after));
+        if (after != ~0ull) {
+            printf("FAIL: hbmpc_stream_pool_retain left the release threshold at %llu\n", (unsigned long long)after);
+            return 1;
+        }
+        printf("release threshold of the device's pool raised from %llu: freed blocks stay in the pool\n", (unsigned long long)before);
     } else {
         printf("default release threshold: the pool returns freed blocks to the driver at every synchronisation\n");
     }

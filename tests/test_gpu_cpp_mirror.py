@@ -57,13 +57,16 @@ def test_pool_allocated_caller_buffers():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
     p = subprocess.run([bin_], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "pool buffers passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+    # the pool was put into the supported configuration by the library's own call (hbmpc_stream_pool_retain), from the platform's default
+    assert "release threshold of the device's pool raised from 0:" in p.stdout, p.stdout[:500]
 
 
 @pytest.mark.gpu
 @pytest.mark.xfail(strict=False, reason="UNSUPPORTED configuration (include/hbmpc_hip.h, 'Device buffers'): a hipMallocAsync pool at its default "
                                         "release threshold returns memory to the driver at every synchronisation; on ROCm 7.2 / gfx950 blocks it "
                                         "re-acquires are then read through stale cache lines (every second episode wrong, "
-                                        "profiles/r02_pool_buffers_default_threshold.txt) -- nothing a library can detect or prevent")
+                                        "profiles/r02_pool_buffers_default_threshold.txt); "
+                                        "hbmpc_stream_pool_release_threshold reports that configuration and hbmpc_stream_pool_retain repairs it")
 def test_pool_allocated_caller_buffers_default_release_threshold():
     """the same episodes with the pool's DEFAULT release threshold: recorded as an expected failure (an XPASS means the
     platform no longer shows the stale lines), so that the outcome is in the test report instead of a print"""
