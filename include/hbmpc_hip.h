@@ -607,6 +607,24 @@ ShareErrorCode hbmpc_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const U256
 ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
                                                          size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, size_t list_row0, size_t list_rows,
                                                          size_t K, const hbmpc_list_slice* slices, size_t n_slices, void* stream);
+/* The same with the OTHER rows -- everything outside [list_row0, list_row0 + list_rows): what the parties send the verifiers --
+ * written party-major to others_out_dev instead of y_out[row][G]: row number r' among them (r' = row below the lists, row - list_rows
+ * above) of chunk (party j, batch element k) goes to
+ *     others_out_dev + (j * (n - list_rows) + r') * K + k  elements.
+ * A sender's shares for ALL verifiers are then one contiguous row of (n - list_rows) K elements, and the verifiers' decodes are ONE
+ * call over (verifier, k) chunks with sender rows (n - list_rows) K apart instead of one call per verifier -- at the reference's own
+ * batch sizes (K of 7 000 .. 15 000 columns, n = 16) thirty launches of 10 - 13 us each become three (profiles/r04_protocol_batch_sizes.txt).
+ * others_out_dev holds parties * (n - list_rows) * K elements (below 4 GiB); y_out_dev (n * G elements) is workspace here: its contents
+ * are unspecified.  Shapes the list kernel covers (hbmpc_dev_apply_rows_lists_in_kernel says which: Fr, 5 .. 16 rows, large batches) write
+ * both kinds of rows from the kernel that computes them; every other shape computes y_out and copies -- same bytes either way. */
+ShareErrorCode hbmpc_dev_vandermonde_apply_rows_split(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n, size_t d,
+                                                      U256* tmp_dev, U256* y_out_dev, size_t list_row0, size_t list_rows, size_t K,
+                                                      const hbmpc_list_slice* slices, size_t n_slices, U256* others_out_dev, void* stream);
+ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows_split(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                         size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, size_t list_row0, size_t list_rows,
+                                                         size_t K, const hbmpc_list_slice* slices, size_t n_slices, uint64_t* others_out_dev,
+                                                         void* stream);
+ShareErrorCode hbmpc_dev_apply_rows_lists_in_kernel(hbmpc_ctx* ctx, size_t G, size_t n, size_t d, int* yes_out);
 /* In-place wire path -- no pack / unpack pass.  A payload that starts 8 bytes before a 32-byte boundary has its
  * elements 32-byte aligned, so the encode kernel writes the payload bodies itself and the decode reads them where
  * they arrived:

@@ -51,6 +51,12 @@ struct Calls {
         return gl ? hbmpc_gl_dev_vandermonde_apply_rows_lists(c, (const uint64_t*)x, stride, G, n, d, (uint64_t*)tmp, (uint64_t*)y, row0, rows, K, sl, nsl, s)
                   : hbmpc_dev_vandermonde_apply_rows_lists(c, (const U256*)x, stride, G, n, d, (U256*)tmp, (U256*)y, row0, rows, K, sl, nsl, s);
     }
+    ShareErrorCode apply_rows_split(hbmpc_ctx* c, const void* x, size_t stride, size_t G, size_t n, size_t d, void* tmp, void* y, size_t row0,
+                                    size_t rows, size_t K, const hbmpc_list_slice* sl, size_t nsl, void* others, void* s) const {
+        return gl ? hbmpc_gl_dev_vandermonde_apply_rows_split(c, (const uint64_t*)x, stride, G, n, d, (uint64_t*)tmp, (uint64_t*)y, row0, rows, K, sl, nsl,
+                                                              (uint64_t*)others, s)
+                  : hbmpc_dev_vandermonde_apply_rows_split(c, (const U256*)x, stride, G, n, d, (U256*)tmp, (U256*)y, row0, rows, K, sl, nsl, (U256*)others, s);
+    }
     ShareErrorCode interpolate_c0(hbmpc_ctx* c, const size_t* ids, size_t S, const void* ev, size_t stride, size_t G, size_t n, void* tmp,
                                   void* c0, uint32_t* deg, void* s) const {
         return gl ? hbmpc_gl_dev_batch_interpolate_c0(c, ids, S, (const uint64_t*)ev, stride, G, n, (uint64_t*)tmp, (uint64_t*)c0, deg, s)
@@ -228,20 +234,27 @@ struct FpMul : hbmpc_pipe {
 // sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied.
 struct Producer : hbmpc_pipe {
     size_t n, t, K;
+    size_t dealers_together_max = 16384;  // above: a launch per dealer (the matrix-core encode, each fills the chip)
     Producer(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : hbmpc_pipe(cx, s), n(n_), t(t_), K(K_) {}
     void deal_one(const unsigned char* coeffs, size_t deg, unsigned char* S) {
         // compute_shares of every dealer's K polynomials: coeffs [dealer][K][deg + 1] -> S [dealer][recipient][K] is the party-batched
-        // encode's layout, so a small batch (the wave-per-chunk kernels: one launch whatever the number of dealers) takes one call
-        // instead of n launches of a few microseconds each; large batches keep a launch per dealer (each fills the chip)
+        // encode's layout.  A launch per dealer fills the chip only from some tens of thousands of polynomials; below that the dealers go
+        // together: up to 2 048 chunks per call through the wave-per-chunk kernels, a mid-size batch in ONE launch of the lane-per-polynomial
+        // kernels over (dealer, polynomial) -- at the reference's own batch sizes (K ~ 7 000 .. 15 000, n = 16) 16 launches of 10 us each
+        // were 45 % of the producers' time (profiles/r04_protocol_batch_sizes.txt)
+        auto together = [&](size_t p, size_t cnt) {
+            const unsigned char* co = coeffs + p * K * (deg + 1) * f.eb;
+            unsigned char* out = S + p * n * K * f.eb;
+            PL(f.gl ? hbmpc_gl_dev_vandermonde_apply_parties(ctx, (const uint64_t*)co, K, n, deg, cnt, (uint64_t*)out, stream)
+                    : hbmpc_dev_vandermonde_apply_parties(ctx, (const U256*)co, K, n, deg, cnt, (U256*)out, stream));
+        };
         if (K <= 1024) {  // as many dealers per call as the wave-per-chunk kernels take in one launch (2048 chunks over all of them)
             const size_t per = 2048 / K;
-            for (size_t p = 0; p < n; p += per) {
-                const size_t cnt = n - p < per ? n - p : per;
-                const unsigned char* co = coeffs + p * K * (deg + 1) * f.eb;
-                unsigned char* out = S + p * n * K * f.eb;
-                PL(f.gl ? hbmpc_gl_dev_vandermonde_apply_parties(ctx, (const uint64_t*)co, K, n, deg, cnt, (uint64_t*)out, stream)
-                        : hbmpc_dev_vandermonde_apply_parties(ctx, (const U256*)co, K, n, deg, cnt, (U256*)out, stream));
-            }
+            for (size_t p = 0; p < n; p += per) together(p, n - p < per ? n - p : per);
+            return;
+        }
+        if (K <= dealers_together_max) {
+            together(0, n);
             return;
         }
         for (size_t p = 0; p < n; ++p)  // dealer p: compute_shares of its K polynomials
@@ -251,8 +264,20 @@ struct Producer : hbmpc_pipe {
     // workspace of the shapes that have to be transposed first).  Rows [row0, row0 + rows) of the result are the parties' OUTPUT:
     // they are written as the per-party lists [k][row] the reference returns, where `lists` says; the other rows -- what the
     // parties send the verifiers -- to y[row][party, k]
-    void mix(const unsigned char* S, unsigned char* x, unsigned char* y, size_t row0, size_t rows, const std::vector<Slice>& lists) {
-        PL(f.apply_rows_lists(ctx, S, n * K, n * K, n, n - 1, x, y, row0, rows, K, lists.data(), lists.size(), stream));
+    // with `others`: the verifiers' rows party-major (hbmpc_dev_vandermonde_apply_rows_split): others[(party (n - rows) + r') K + k]
+    void mix(const unsigned char* S, unsigned char* x, unsigned char* y, size_t row0, size_t rows, const std::vector<Slice>& lists,
+             unsigned char* others = nullptr) {
+        if (others) PL(f.apply_rows_split(ctx, S, n * K, n * K, n, n - 1, x, y, row0, rows, K, lists.data(), lists.size(), others, stream));
+        else PL(f.apply_rows_lists(ctx, S, n * K, n * K, n, n - 1, x, y, row0, rows, K, lists.data(), lists.size(), stream));
+    }
+    // Mid-size batches (the reference's own: some thousands of columns per dealer): one verifier's decode is a launch of ~10 us that
+    // does not fill the chip, and there are 2t (RanSha) or 2 (n - t - 1) (RanDouSha) of them.  Where the mixing kernel can write the
+    // verifiers' rows party-major, all verifiers of a kind are ONE decode over (verifier, column) chunks (profiles/r04_protocol_batch_sizes.txt).
+    // Larger batches (from 2^16 columns a verifier fills the chip by itself; the party-major block must stay below 4 GiB) keep a call each.
+    bool verifiers_together(size_t nver) const {
+        int yes = 0;
+        if (f.gl || nver < 2 || K >= ((size_t)1 << 16) || n * nver * K * f.eb >= ((size_t)1 << 32)) return false;
+        return hbmpc_dev_apply_rows_lists_in_kernel(ctx, n * K, n, n - 1, &yes) == ShareSuccess && yes != 0;
     }
     void run() override {
         deal();
@@ -265,9 +290,9 @@ struct Producer : hbmpc_pipe {
 // share_gen.rs:497 -- with degree t a decode with no OEC round)
 struct RanSha : Producer {
     size_t nout;
-    unsigned char *coeffs, *S, *x, *y, *poly, *out;
+    unsigned char *coeffs, *S, *x, *y, *yv = nullptr, *poly, *out;
     uint8_t* status;
-    bool grouped;
+    bool grouped, together;
     std::vector<size_t> ids;
     std::vector<Slice> split;  // set by Preprocessing: where the output slices go instead of `out`
     static size_t checked_nout(size_t n, size_t t, size_t K) {  // before the arena is sized from n - 2t
@@ -279,12 +304,15 @@ struct RanSha : Producer {
         if (verify_senders == 0) verify_senders = 2 * t + 1;
         if (verify_senders < 2 * t + 1 || verify_senders > n) throw PipeError{InvalidInput};
         grouped = 2 * t * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: workspace for all of them
-        const size_t poly_el = K * (grouped && 2 * t > t + 1 ? 2 * t : t + 1), status_b = grouped ? 2 * t * K + 1 : K;
-        arena((n * K * (t + 1) + 3 * n * n * K + poly_el + n * nout) * f.eb + status_b + (1 << 14));
+        together = !grouped && verify_senders == 2 * t + 1 && verifiers_together(2 * t);
+        const bool all = grouped || together;
+        const size_t poly_el = K * (all && 2 * t > t + 1 ? 2 * t : t + 1), status_b = all ? 2 * t * K + 1 : K;
+        arena((n * K * (t + 1) + 3 * n * n * K + (together ? 2 * t * n * K : 0) + poly_el + n * nout) * f.eb + status_b + (1 << 14));
         coeffs = take("coeffs", n * K * (t + 1));  // [dealer][K][t + 1]
         S = take("S", n * n * K);                  // [dealer][recipient][K]
         x = take("x", n * n * K);
         y = take("y", n * n * K);                  // [row i][party][K]
+        if (together) yv = take("yv", 2 * t * n * K);  // [party][verifier i][K]
         poly = take("poly", poly_el);
         status = take_bytes("status", status_b, K);
         summ = reinterpret_cast<hbmpc_recover_summary*>(take_bytes("summary", 64, 16));
@@ -295,12 +323,17 @@ struct RanSha : Producer {
     void deal() override { deal_one(coeffs, t, S); }
     void finish() override {  // everything after the dealers' messages have arrived
         // rows 2t .. n - 1 of every batch element are the output, per party in the order [k][i - 2t]  (share_gen.rs:199-203)
-        mix(S, x, y, 2 * t, n - 2 * t, split.empty() ? std::vector<Slice>{{out, nout, 0, K}} : split);
+        mix(S, x, y, 2 * t, n - 2 * t, split.empty() ? std::vector<Slice>{{out, nout, 0, K}} : split, yv);
         clear_bad();
         // verifiers 0 .. 2t - 1: recover_secret of the K columns + exact-degree test (share_gen.rs:516-530); verifier i's sender rows are
         // y + i n K: all of them in one call (one launch for a small batch: `grouped` sized the workspace for it)
         const size_t nver = 2 * t;
         if (nver == 0) return;
+        if (together) {  // sender j's row: yv + j nver K, verifier i's columns at i K inside it -- groups that follow each other
+            PL(hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)yv, nver * K, K, n, t, nver, K, (U256*)poly, status, summ, bad,
+                                                      stream));
+            return;
+        }
         if (grouped) {
             PL(f.gl ? hbmpc_gl_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const uint64_t*)y, K, K, n, t, nver, n * K, (uint64_t*)poly,
                                                                 status, summ, bad, stream)
@@ -321,8 +354,9 @@ struct RanSha : Producer {
 struct RanDouSha : Producer {
     size_t nout;
     unsigned char *coeffs_t, *coeffs_2t, *S_t, *S_2t, *x, *y_t, *y_2t, *poly, *c0_t, *c0_2t, *out_t, *out_2t, *sel_t, *sel_2t, *st_t, *st_2t;
+    unsigned char *yv_t = nullptr, *yv_2t = nullptr;
     uint32_t *deg_t, *deg_2t;
-    bool grouped;
+    bool grouped, together;
     std::vector<size_t> ids;
     std::vector<Slice> split_t, split_2t;
     static size_t checked_nout(size_t n, size_t t, size_t K) {
@@ -331,11 +365,13 @@ struct RanDouSha : Producer {
     }
     RanDouSha(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
         grouped = (n - t - 1) * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: room for all their results
-        const size_t vr = grouped ? n - t - 1 : 1;
-        arena((n * K * (3 * t + 2) + 5 * n * n * K + K * n + (2 + 4 * vr) * K + 2 * n * nout) * f.eb + (8 + 2 * vr) * K + (1 << 14));
+        together = !grouped && 2 * t < n && verifiers_together(n - t - 1);
+        const size_t vr = grouped || together ? n - t - 1 : 1;
+        arena((n * K * (3 * t + 2) + 5 * n * n * K + (together ? 2 * vr * n * K : 0) + K * n + (2 + 4 * vr) * K + 2 * n * nout) * f.eb + (8 + 2 * vr) * K + (1 << 14));
         coeffs_t = take("coeffs_t", n * K * (t + 1)), coeffs_2t = take("coeffs_2t", n * K * (2 * t + 1));
         S_t = take("S_t", n * n * K), S_2t = take("S_2t", n * n * K);
         x = take("x", n * n * K), y_t = take("y_t", n * n * K), y_2t = take("y_2t", n * n * K);
+        if (together) yv_t = take("yv_t", vr * n * K), yv_2t = take("yv_2t", vr * n * K);  // [party][verifier][K]
         poly = take("poly", K * n);  // workspace of the verifier interpolations that have no c0-only kernel
         c0_t = take("c0_t", K), c0_2t = take("c0_2t", K);
         deg_t = reinterpret_cast<uint32_t*>(take_bytes("deg_t", 4 * K, K)), deg_2t = reinterpret_cast<uint32_t*>(take_bytes("deg_2t", 4 * K, K));
@@ -351,12 +387,19 @@ struct RanDouSha : Producer {
     }
     void finish() override {
         // RanDouShaNode::init_batch steps 1, 2, 4-5: rows 0 .. t are the output, per party in the order [k][i]  (ran_dou_sha/mod.rs:314-331)
-        mix(S_t, x, y_t, 0, t + 1, split_t.empty() ? std::vector<Slice>{{out_t, nout, 0, K}} : split_t);
-        mix(S_2t, x, y_2t, 0, t + 1, split_2t.empty() ? std::vector<Slice>{{out_2t, nout, 0, K}} : split_2t);
+        mix(S_t, x, y_t, 0, t + 1, split_t.empty() ? std::vector<Slice>{{out_t, nout, 0, K}} : split_t, yv_t);
+        mix(S_2t, x, y_2t, 0, t + 1, split_2t.empty() ? std::vector<Slice>{{out_2t, nout, 0, K}} : split_2t, yv_2t);
         clear_bad();
         // step 3: verifiers t + 1 .. n - 1 interpolate both sharings through all n shares and test the degrees and the constant terms
         // (:586-602) -- they keep nothing else of them
         const size_t nver = n - t - 1, v0 = (t + 1) * n * K * f.eb;  // verifier i's sender rows: y + i n K
+        if (together) {  // sender j's row: yv + j nver K, verifier i's columns at i K inside it -- groups that follow each other
+            PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)yv_t, nver * K, K, n, t, nver, K, (U256*)poly, (U256*)sel_t, st_t, stream));
+            PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)yv_2t, nver * K, K, n, 2 * t, nver, K, (U256*)poly, (U256*)sel_2t, st_2t,
+                                                          stream));
+            PL(hbmpc_dev_check_double_share_sel(ctx, sel_t, st_t, sel_2t, st_2t, nver * K, K, t, bad, stream));
+            return;
+        }
         if (!f.gl && 2 * t < n && grouped) {  // all verifiers in one call each (hbmpc_dev_interpolate_degree_check_strided)
             PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)(y_t + v0), K, K, n, t, nver, n * K, (U256*)poly, (U256*)sel_t, st_t,
                                                           stream));

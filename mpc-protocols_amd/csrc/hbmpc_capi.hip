@@ -671,6 +671,7 @@ struct ListSpec {
     size_t row0, rows, K;
     const hbmpc_list_slice* slices;
     size_t n_slices;
+    void* others = nullptr;  // non-null: the rows outside the lists go here, party-major: others[(j (n - rows) + r') K + k] (hbmpc_dev_vandermonde_apply_rows_split)
 };
 static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t dp1, EvalOut y, hipStream_t s,
                           ShareErrorCode* rc_out, size_t x_row_stride = 0, const ListSpec* lists = nullptr) {
@@ -731,6 +732,7 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
             }
             if (lists) {
                 b.list_row0 = (int)lists->row0, b.list_rows = (int)lists->rows, b.list_K = (uint32_t)lists->K;
+                if (lists->others) b.other_stride = (uint32_t)((n - lists->rows) * lists->K);
                 for (size_t k = 0; k < 2; ++k) {
                     const bool have = k < lists->n_slices;
                     b.list[k].dst = have ? (uint8_t*)lists->slices[k].dst_dev : nullptr;
@@ -741,7 +743,7 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
             }
             for (unsigned p = 0; p < y.parties && ok; ++p) {  // party-batched calls: one launch per party
                 b.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
-                b.out = (uint8_t*)y.y + (size_t)p * n * b.out_stride * 32;
+                b.out = lists && lists->others ? (uint8_t*)lists->others : (uint8_t*)y.y + (size_t)p * n * b.out_stride * 32;
                 ok = launch_mfma_bfly_a(mi, b, ctx->device, s) || launch_mfma_bfly_b(mi, b, ctx->device, s) ||
                      launch_mfma_bfly_c(mi, b, ctx->device, s) || launch_mfma_bfly_d(mi, b, ctx->device, s);
                 if (!ok && p > 0) return false;  // cannot happen: the first party's launch decides
@@ -1771,6 +1773,8 @@ static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x
     ShareErrorCode rc_mf = ShareSuccess;
     const bool mf_shape = ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && dp1 >= 2 && dp1 <= MF_BFLY_MAX_M &&
                           size >= 8 && n <= 255 && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 && G * 32 < ((size_t)1 << 32);
+    if (lists && lists->others && (lists->rows >= n || (G / lists->K) * (n - lists->rows) * lists->K * 32 >= ((size_t)1 << 32)))
+        return fail(ctx, InvalidInput, "party-major other rows: needs a row outside the lists and less than 4 GiB of them");
     // the list rows straight from the kernel that computes them (k_mfma_bfly<.., LISTS>): one role, G < 2^32 chunks
     if (lists && mf_shape && ctx->list_rows_in_kernel && try_mfma_eval(ctx, (const uint32_t*)x_rows, G, n, dp1, EvalOut{(uint32_t*)y, 0, 1}, s, &rc_mf, x_row_stride, lists)) {
         if (rc_mf != ShareSuccess) return rc_mf;
@@ -1780,6 +1784,16 @@ static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x
     auto copy_lists = [&]() -> ShareErrorCode {  // every row is in y[row][G]: the list rows are copied out per slice
         if (!lists) return ShareSuccess;
         const size_t parties = G / lists->K;
+        if (lists->others) {  // and the other rows into their party-major place: per row a [parties][K] block copy
+            const size_t eb = ebytes(ctx), nother = n - lists->rows;
+            for (size_t row = 0, rp = 0; row < n; ++row) {
+                if (row >= lists->row0 && row < lists->row0 + lists->rows) continue;
+                const ShareErrorCode rc = hbmpc_memcpy_d2d_rows(ctx, (uint8_t*)lists->others + rp * lists->K * eb, nother * lists->K * eb,
+                                                                (const uint8_t*)y + row * G * eb, lists->K * eb, lists->K * eb, parties, stream);
+                if (rc != ShareSuccess) return rc;
+                ++rp;
+            }
+        }
         for (size_t k = 0; k < lists->n_slices; ++k) {
             const hbmpc_list_slice& sl = lists->slices[k];
             const ShareErrorCode rc = hbmpc_dev_transpose(ctx, (const uint8_t*)y + (lists->row0 * G + sl.k0) * ebytes(ctx), lists->rows, sl.count, G,
@@ -1811,9 +1825,33 @@ extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, co
     return eval_rows_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, stream);
 }
 static ShareErrorCode eval_rows_lists_any(hbmpc_ctx* ctx, const void* x_rows, size_t x_row_stride, size_t G, size_t n, size_t d, void* tmp, void* y,
-                                          size_t list_row0, size_t list_rows, size_t K, const hbmpc_list_slice* slices, size_t n_slices, void* stream) {
-    const ListSpec ls{list_row0, list_rows, K, slices, n_slices};
+                                          size_t list_row0, size_t list_rows, size_t K, const hbmpc_list_slice* slices, size_t n_slices, void* stream,
+                                          void* others = nullptr, bool want_others = false) {
+    if (ctx && want_others && !others) return fail(ctx, InvalidInput, "null buffer");
+    const ListSpec ls{list_row0, list_rows, K, slices, n_slices, others};
     return eval_rows_any(ctx, x_rows, x_row_stride, G, n, d, tmp, y, stream, &ls);
+}
+// would the mixing step write its lists (and party-major other rows) from the kernel that computes them?  (otherwise: all rows to y, then copies)
+extern "C" ShareErrorCode hbmpc_dev_apply_rows_lists_in_kernel(hbmpc_ctx* ctx, size_t G, size_t n, size_t d, int* yes_out) {
+    if (!ctx || !yes_out) return InvalidInput;
+    const size_t size = domain_size(n), dp1 = d + 1;
+    *yes_out = ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && ctx->list_rows_in_kernel && dp1 >= 2 &&
+               dp1 >= 5 && dp1 <= MF_BFLY_MAX_M && size >= 8 && size <= 16 && n > size / 2 &&  // tu_mfma_bfly.inc: launch_lists
+               (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 && G * 32 < ((size_t)1 << 32);
+    return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_rows_split(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n, size_t d,
+                                                                 U256* tmp_dev, U256* y_out_dev, size_t list_row0, size_t list_rows, size_t K,
+                                                                 const hbmpc_list_slice* slices, size_t n_slices, U256* others_out_dev, void* stream) {
+    REQ_FR(ctx);
+    return eval_rows_lists_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, list_row0, list_rows, K, slices, n_slices, stream, others_out_dev, true);
+}
+extern "C" ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows_split(hbmpc_ctx* ctx, const uint64_t* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
+                                                                    size_t d, uint64_t* tmp_dev, uint64_t* y_out_dev, size_t list_row0, size_t list_rows,
+                                                                    size_t K, const hbmpc_list_slice* slices, size_t n_slices, uint64_t* others_out_dev,
+                                                                    void* stream) {
+    REQ_GL(ctx);
+    return eval_rows_lists_any(ctx, x_rows_dev, x_row_stride, G, n, d, tmp_dev, y_out_dev, list_row0, list_rows, K, slices, n_slices, stream, others_out_dev, true);
 }
 extern "C" ShareErrorCode hbmpc_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n,
                                                                  size_t d, U256* tmp_dev, U256* y_out_dev, size_t list_row0, size_t list_rows,

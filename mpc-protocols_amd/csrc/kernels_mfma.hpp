@@ -276,6 +276,10 @@ struct MfmaRowsArgs {
     // (share_gen.rs:199-203, ran_dou_sha/mod.rs:314-331: per party [k][row]); list_rows = 0: every row is party-major
     int list_row0, list_rows;
     uint32_t list_K;
+    // with lists: the OTHER rows (what the parties send the verifiers) party-major, other_stride != 0: row number r' among them (r' = row
+    // below the list rows, row - list_rows above) of chunk (j, k) goes to out + ((j other_stride + r' list_K + k) * 32, other_stride =
+    // (n - list_rows) list_K -- every verifier's column block of a sender is then one contiguous row of (verifier, k) chunks
+    uint32_t other_stride;
     // k_mfma_rows<.., SUB> (decode): the senders' values are DIFFERENCES formed as they are loaded (the shares Multiply opens,
     // mul/multiplication.rs:417-426): chunk g < sub_half is in[row][g] - sub_x[row][g], chunk g >= sub_half is
     // in2[row][g - sub_half] - sub_x2[row][g - sub_half]  (mod r); sub_half is a multiple of 32, rows are row_stride elements apart

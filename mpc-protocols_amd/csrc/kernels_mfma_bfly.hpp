@@ -91,6 +91,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         const size_t b = a.out_party_major ? a.G * 32 : a.G * a.out_stride * 32;
         return b < 0xffffffe0ull ? b : 0xffffffe0ull;
     }());
+    // party-major other rows: a row's stores end (parties - 1) other_stride + list_K elements behind its base (the host keeps it below 2^32 bytes)
+    [[maybe_unused]] const uint32_t other_bytes = LISTS && a.other_stride != 0 ? (uint32_t)(((a.G / a.list_K - 1) * (size_t)a.other_stride + a.list_K) * 32) : 0u;
     // sc: this lane's 16 bytes of list row 0 of its chunk (0: the chunk has no list destination), see MfmaRowsArgs::list
     auto store_row = [&](uint8_t* out, uint32_t k, bool exists, bool live, uint32_t qo, const uint32_t (&Rw)[4], uint64_t sc) {
         if (LISTS && k - (uint32_t)a.list_row0 < (uint32_t)a.list_rows) {  // wave-uniform
@@ -99,10 +101,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         }
         if (DEG && a.store_rows != 0 && k >= (uint32_t)a.store_rows) exists = false;
         uint8_t* qb = a.out_party_major ? out + (size_t)k * a.out_stride * 32 : out + (size_t)k * 32;  // wave-uniform
+        uint32_t bound = row_bytes;
+        if (LISTS && a.other_stride != 0) {  // the other rows party-major (MfmaRowsArgs::other_stride): qo is the lane's (party, k) offset
+            const uint32_t rp = k < (uint32_t)a.list_row0 ? k : k - (uint32_t)a.list_rows;
+            qb = out + (size_t)rp * a.list_K * 32;
+            bound = other_bytes;
+        }
         if constexpr (STATIC) {
             v4i val;
             val[0] = (int)Rw[0], val[1] = (int)Rw[1], val[2] = (int)Rw[2], val[3] = (int)Rw[3];
-            __builtin_amdgcn_raw_buffer_store_b128(val, rt_rsrc(qb, exists ? row_bytes : 0u), (int)(live ? qo : RT_OOB), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(val, rt_rsrc(qb, exists ? bound : 0u), (int)(live ? qo : RT_OOB), 0, 0);
         } else {
             if (exists && live) *reinterpret_cast<uint4*>(qb + qo) = make_uint4(Rw[0], Rw[1], Rw[2], Rw[3]);
         }
@@ -112,10 +120,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
         const size_t gi = t * 32 + c;
         const bool live = gi < a.G;
         const uint32_t g = (uint32_t)(live ? gi : a.G - 1);
-        const uint32_t qo = g * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
+        uint32_t qo = g * (a.out_party_major ? 32u : (uint32_t)a.out_stride * 32u) + 16u * h;
         uint64_t sc = 0;
         if (LISTS && live) {
             const uint32_t j = g / a.list_K, kk = g - j * a.list_K;
+            if (a.other_stride != 0) qo = (j * a.other_stride + kk) * 32u + 16u * h;
             const int s = kk - a.list[0].k0 < a.list[0].count ? 0 : kk - a.list[1].k0 < a.list[1].count ? 1 : -1;
             if (s >= 0) {
                 const MfmaRowsArgs::ListSlice sl = s ? a.list[1] : a.list[0];

@@ -539,6 +539,25 @@ class Engine:
         return self._f("dev_vandermonde_apply_rows")(self.ctx, C.c_void_p(x_rows_d), C.c_size_t(x_row_stride), C.c_size_t(G), C.c_size_t(n),
                                                        C.c_size_t(d), C.c_void_p(tmp_d), C.c_void_p(y_d), C.c_void_p(stream))
 
+    def dev_vandermonde_apply_rows_split(self, x_rows_d, x_row_stride, G, n, d, tmp_d, y_d, list_row0, list_rows, K, slices, others_d, stream=0):
+        """The producers' mixing step: output rows [list_row0, list_row0 + list_rows) as the parties' lists (slices: (dst_dev, party_stride,
+        k0, count), at most two), the other rows party-major to others_d [(party (n - list_rows) + r') K + k]
+        (hbmpc_dev_vandermonde_apply_rows_split); others_d = None: the other rows to y_d[row][G] (hbmpc_dev_vandermonde_apply_rows_lists)"""
+        class _Slice(C.Structure):
+            _fields_ = [("dst_dev", C.c_void_p), ("party_stride", C.c_size_t), ("k0", C.c_size_t), ("count", C.c_size_t)]
+        arr = (_Slice * len(slices))(*[_Slice(*sl) for sl in slices])
+        common = (self.ctx, C.c_void_p(x_rows_d), C.c_size_t(x_row_stride), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.c_void_p(tmp_d),
+                  C.c_void_p(y_d), C.c_size_t(list_row0), C.c_size_t(list_rows), C.c_size_t(K), arr, C.c_size_t(len(slices)))
+        if others_d is None:
+            return self._f("dev_vandermonde_apply_rows_lists")(*common, C.c_void_p(stream))
+        return self._f("dev_vandermonde_apply_rows_split")(*common, C.c_void_p(others_d), C.c_void_p(stream))
+
+    def apply_rows_lists_in_kernel(self, G, n, d) -> bool:
+        yes = C.c_int(0)
+        rc = self.L.hbmpc_dev_apply_rows_lists_in_kernel(self.ctx, C.c_size_t(G), C.c_size_t(n), C.c_size_t(d), C.byref(yes))
+        assert rc == 0, self.last_error()
+        return bool(yes.value)
+
     def dev_vandermonde_apply_strided(self, x_d, G, n, d, y_d, y_row_stride, stream=0):
         return self._f("dev_vandermonde_apply_strided")(self.ctx, C.c_void_p(x_d), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
                                                         C.c_void_p(y_d), C.c_size_t(y_row_stride), C.c_void_p(stream))

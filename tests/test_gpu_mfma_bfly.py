@@ -206,6 +206,58 @@ def test_inputs_given_as_rows(eng, n, d, G):
         assert rc != 0 and "workspace" in eng.last_error()
 
 
+@pytest.mark.parametrize("n,K,row0,rows", [(16, 1500, 10, 6), (16, 1237, 0, 6), (7, 3001, 4, 3), (13, 2000, 0, 5), (4, 5000, 2, 2), (16, 40, 10, 6),
+                                           (16, 1500, 0, 15), (16, 1500, 15, 1)])
+def test_mixing_step_with_lists_and_party_major_other_rows(eng, n, K, row0, rows):
+    """hbmpc_dev_vandermonde_apply_rows_split: the n x n mixing step of the producers over G = n K chunks (party j, batch element k) with
+    output rows [row0, row0 + rows) written as the parties' lists (two slices) and every other row party-major -- from the kernel that
+    computes them (k_mfma_bfly<.., LISTS>: 5 .. 16 rows, large batches) and through the copies (every other shape;
+    hbmpc_set_producer_fusion(0)): both against the plain y[row][G] of hbmpc_dev_vandermonde_apply_rows, itself checked against the oracle"""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    G, d = n * K, n - 1
+    x = polys(17 * n + K, G, d)
+    xr = torch.as_tensor(np.ascontiguousarray(x.transpose(1, 0, 2)).view(np.int64), device=dev)
+    tmp = torch.empty((G, d + 1, 4), dtype=torch.int64, device=dev)
+    y = torch.full((n, G, 4), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_vandermonde_apply_rows(xr.data_ptr(), G, G, n, d, tmp.data_ptr(), y.data_ptr()) == 0, eng.last_error()
+    eng.sync()
+    rc0, y0 = O.vandermonde_apply(x, n, d)
+    y_np = y.cpu().numpy().view(np.uint64)
+    assert rc0 == 0 and np.array_equal(y_np, y0)
+    nother = n - rows
+    other_rows = [r for r in range(n) if not row0 <= r < row0 + rows]
+    want_others = y_np.reshape(n, n, K, 4)[other_rows].transpose(1, 0, 2, 3)            # [party][r'][K]
+    want_lists = y_np.reshape(n, n, K, 4)[row0:row0 + rows].transpose(1, 2, 0, 3)         # [party][K][row]
+    k1 = K // 3                                                                           # two slices: [0, k1) and [k1 + 1, K): element k1 is dropped
+    in_kernel = eng.apply_rows_lists_in_kernel(G, n, d)
+    assert in_kernel == (5 <= n <= 16 and (G + 31) // 32 > 512)
+    for fused in (1, 0):
+        assert eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(fused)) == 0
+        assert eng.apply_rows_lists_in_kernel(G, n, d) == (in_kernel and fused == 1)
+        la = torch.full((n, k1, rows, 4), -1, dtype=torch.int64, device=dev)
+        lb = torch.full((n, K - k1 - 1 + 2, rows, 4), -1, dtype=torch.int64, device=dev)  # party stride two elements of `rows` wider than the slice
+        others = torch.full((n, nother, K, 4), -1, dtype=torch.int64, device=dev)
+        y.fill_(-1)
+        torch.cuda.synchronize()
+        slices = [(la.data_ptr(), k1 * rows, 0, k1), (lb.data_ptr(), (K - k1 + 1) * rows, k1 + 1, K - k1 - 1)]
+        rc = eng.dev_vandermonde_apply_rows_split(xr.data_ptr(), G, G, n, d, tmp.data_ptr(), y.data_ptr(), row0, rows, K, slices, others.data_ptr())
+        assert rc == 0, eng.last_error()
+        eng.sync()
+        assert np.array_equal(others.cpu().numpy().view(np.uint64), want_others), fused
+        assert np.array_equal(la.cpu().numpy().view(np.uint64), want_lists[:, :k1]), fused
+        got_b = lb.cpu().numpy().view(np.uint64)
+        assert np.array_equal(got_b[:, :K - k1 - 1], want_lists[:, k1 + 1:]) and np.all(got_b[:, K - k1 - 1:] == np.uint64(2**64 - 1)), fused
+    assert eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(1)) == 0
+    # no buffer for the other rows, every row a list row: refused
+    rc = eng._f("dev_vandermonde_apply_rows_split")(eng.ctx, C.c_void_p(xr.data_ptr()), C.c_size_t(G), C.c_size_t(G), C.c_size_t(n), C.c_size_t(d),
+                                                    C.c_void_p(tmp.data_ptr()), C.c_void_p(y.data_ptr()), C.c_size_t(row0), C.c_size_t(rows), C.c_size_t(K),
+                                                    None, C.c_size_t(0), C.c_void_p(0), C.c_void_p(0))
+    assert rc != 0
+
+
 @pytest.mark.parametrize("n,G,stride_pad", [(16, 20000 + 5, 0), (16, 40000, 64), (8, 33000 + 1, 0)])
 def test_full_domain_interpolation_is_the_inverse_transform(eng, n, G, stride_pad):
     """hbmpc_dev_batch_interpolate through all n shares of a full domain (the RanDouSha verifier, ran_dou_sha/mod.rs:569-602) on the

@@ -1,0 +1,62 @@
+"""run_preprocessing's triple part at the batch sizes the reference's node uses (honeybadger/mod.rs:106-120, :1434: 4 096 triple groups
+per batch, i.e. N = 4 096 (2t + 1) triples per party) for the party counts of its tests and benches: device time per run, eager and as a
+HIP graph, of Preprocessing (RanSha -> a, b; DouSha + RanDouSha -> r; TripleGen) and of TripleGen alone.
+    python tools/time_protocol_sizes.py [groups]            (under rocprofv3 --kernel-trace --stats for the launches behind the times)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from __graft_entry__ import load_package
+
+pkg = load_package()
+pl = pkg.pipelines
+eng = pkg.Engine(0)
+dev = torch.device("cuda", 0)
+ts = torch.cuda.Stream(device=dev)
+torch.cuda.set_stream(ts)
+stream = ts.cuda_stream
+groups = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+shapes = [tuple(map(int, a.split(","))) for a in sys.argv[2:]] or [(4, 1), (7, 2), (10, 3), (16, 5)]
+
+
+def rand_fr(*shape):
+    x = torch.randint(0, 1 << 62, shape + (4,), dtype=torch.int64, device=dev)
+    x[..., 3] &= (1 << 60) - 1
+    return x
+
+
+def ev_ms(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+for n, t in shapes:
+    N = groups * (2 * t + 1)
+    pre = pl.Preprocessing(eng, n, t, N, stream)
+    sec0 = {}
+    for ptr, K, deg in ((pre.rs.coeffs, pre.K_rs, t), (pre.rd.coeffs_t, pre.K_rd, t), (pre.rd.coeffs_2t, pre.K_rd, 2 * t)):
+        for p in range(n):
+            co = rand_fr(K, deg + 1)
+            if ptr == pre.rd.coeffs_2t:
+                co[:, 0] = sec0[p]
+            elif ptr == pre.rd.coeffs_t:
+                sec0[p] = co[:, 0].clone()
+            eng.d2d(ptr + p * K * (deg + 1) * 32, co.data_ptr(), K * (deg + 1) * 32, stream)
+            torch.cuda.synchronize()
+    pre.run(check=True)
+    ms_e = ev_ms(lambda: pre.run(check=False))
+    ms_rs = ev_ms(lambda: pre.rs.run(check=False))
+    ms_rd = ev_ms(lambda: pre.rd.run(check=False))
+    ms_tg = ev_ms(lambda: pre.tg.run(check=False))
+    pre.capture()
+    ms_g = ev_ms(pre.replay)
+    print(f"n={n:2d} t={t} N={N:6d} K_rs={pre.K_rs:6d} K_rd={pre.K_rd:6d}: preprocessing {ms_e:.3f} ms eager, {ms_g:.3f} ms graph "
+          f"({N / ms_g * 1e3:.3e} triples/s); RanSha {ms_rs:.3f}  RanDouSha {ms_rd:.3f}  TripleGen {ms_tg:.3f}", flush=True)
+    pre.close()
