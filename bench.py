@@ -1148,26 +1148,27 @@ def pipeline_measurements(eng, torch, dev, stream, ev_time):
         del a, b, r
     # the producers in front of it at the same protocol-sized batch: run_preprocessing's triple part from the dealers' polynomials
     # (RanSha -> a, b; DouSha + RanDouSha -> r; TripleGen).  Launch-bound: ~100 launches, the verifiers' loops most of them.
-    Ns = 100 * (2 * t + 1)
-    pre = pl.Preprocessing(eng, n, t, Ns, stream)
-    sec0 = {}
-    for ptr, K, deg in ((pre.rs.coeffs, pre.K_rs, t), (pre.rd.coeffs_t, pre.K_rd, t), (pre.rd.coeffs_2t, pre.K_rd, 2 * t)):
-        for p in range(n):
-            co = _rand_fr(torch, dev, K, deg + 1)
-            if ptr == pre.rd.coeffs_2t:
-                co[:, 0] = sec0[p]
-            elif ptr == pre.rd.coeffs_t:
-                sec0[p] = co[:, 0].clone()
-            eng.d2d(ptr + p * K * (deg + 1) * 32, co.data_ptr(), K * (deg + 1) * 32, stream)
-            torch.cuda.synchronize()
-    pre.run(check=True)
-    ms_eager = ev_time(lambda: pre.run(check=False), reps=10, warm=2)
-    pre.capture()
-    ms_graph = ev_time(pre.replay, reps=10, warm=2)
-    res["cfg4_preprocessing_1100_triples"] = {"triples": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph,
-                                              "note": "dealers' polynomials -> [c]: RanSha, DouSha + RanDouSha, TripleGen; launch-bound at this size"}
-    pre.close()
-    del sec0
+    for groups_pre in (100, 4096):  # 4096 triple groups per batch: the reference node's own batch size (honeybadger/mod.rs:106-112)
+        Ns = groups_pre * (2 * t + 1)
+        pre = pl.Preprocessing(eng, n, t, Ns, stream)
+        sec0 = {}
+        for ptr, K, deg in ((pre.rs.coeffs, pre.K_rs, t), (pre.rd.coeffs_t, pre.K_rd, t), (pre.rd.coeffs_2t, pre.K_rd, 2 * t)):
+            for p in range(n):
+                co = _rand_fr(torch, dev, K, deg + 1)
+                if ptr == pre.rd.coeffs_2t:
+                    co[:, 0] = sec0[p]
+                elif ptr == pre.rd.coeffs_t:
+                    sec0[p] = co[:, 0].clone()
+                eng.d2d(ptr + p * K * (deg + 1) * 32, co.data_ptr(), K * (deg + 1) * 32, stream)
+                torch.cuda.synchronize()
+        pre.run(check=True)
+        ms_eager = ev_time(lambda: pre.run(check=False), reps=10, warm=2)
+        pre.capture()
+        ms_graph = ev_time(pre.replay, reps=10, warm=2)
+        res[f"cfg4_preprocessing_{Ns}_triples"] = {"triples": Ns, "parties": n, "ms_eager": ms_eager, "ms_hip_graph": ms_graph, "triples_per_s": Ns / min(ms_eager, ms_graph) * 1e3,
+                                                  "note": "dealers' polynomials -> [c]: RanSha, DouSha + RanDouSha, TripleGen" + ("; launch-bound at this size" if groups_pre == 100 else "; the reference node's batch size (4096 triple groups)")}
+        pre.close()
+        del sec0
     # config 5: fpmul, n=16, t=5, 2^18 elements, (k, f) = (16, 4)
     N, k, m = 1 << 18, 16, 4
     fp = setup_fpmul(eng, torch, dev, stream, n, t, N, k, m)
