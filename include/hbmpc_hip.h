@@ -364,6 +364,11 @@ ShareErrorCode hbmpc_dev_batch_interpolate_c0(hbmpc_ctx* ctx, const size_t* ids,
                                               void* stream);
 ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
                                                const uint32_t* degree_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream);
+/* The same when the G entries are several verifiers' results over the same `columns` columns, one verifier after the other (G a multiple
+ * of columns; 0 = G): bad[1] is the first failing COLUMN (entry index mod columns), bad[0] counts entries as before. */
+ShareErrorCode hbmpc_dev_check_double_share_c0_columns(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
+                                                       const uint32_t* degree_2t_dev, size_t G, size_t columns, size_t t, uint32_t* bad_dev,
+                                                       void* stream);
 
 /* ---- layout and verdict steps of the preprocessing producers (RanSha, DouSha, RanDouSha; either field: the element
  * size follows the context) -----------------------------------------------------------------------------------------

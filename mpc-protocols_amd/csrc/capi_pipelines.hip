@@ -274,10 +274,13 @@ struct Producer : hbmpc_pipe {
     // does not fill the chip, and there are 2t (RanSha) or 2 (n - t - 1) (RanDouSha) of them.  Where the mixing kernel can write the
     // verifiers' rows party-major, all verifiers of a kind are ONE decode over (verifier, column) chunks (profiles/r04_protocol_batch_sizes.txt).
     // Larger batches (from 2^16 columns a verifier fills the chip by itself; the party-major block must stay below 4 GiB) keep a call each.
+    // Shapes the list kernel does not cover (Goldilocks, 4-point domains) pay one more pass for the party-major rows (k_rows_party_major):
+    // from three verifiers on that is still fewer launches.
     bool verifiers_together(size_t nver) const {
         int yes = 0;
-        if (f.gl || nver < 2 || K >= ((size_t)1 << 16) || n * nver * K * f.eb >= ((size_t)1 << 32)) return false;
-        return hbmpc_dev_apply_rows_lists_in_kernel(ctx, n * K, n, n - 1, &yes) == ShareSuccess && yes != 0;
+        if (nver < 2 || K >= ((size_t)1 << 16) || n * nver * K * f.eb >= ((size_t)1 << 32)) return false;
+        if (hbmpc_dev_apply_rows_lists_in_kernel(ctx, n * K, n, n - 1, &yes) != ShareSuccess) return false;
+        return yes != 0 || nver >= 3;
     }
     void run() override {
         deal();
@@ -330,8 +333,10 @@ struct RanSha : Producer {
         const size_t nver = 2 * t;
         if (nver == 0) return;
         if (together) {  // sender j's row: yv + j nver K, verifier i's columns at i K inside it -- groups that follow each other
-            PL(hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)yv, nver * K, K, n, t, nver, K, (U256*)poly, status, summ, bad,
-                                                      stream));
+            PL(f.gl ? hbmpc_gl_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const uint64_t*)yv, nver * K, K, n, t, nver, K, (uint64_t*)poly,
+                                                                status, summ, bad, stream)
+                    : hbmpc_dev_recover_check_degree_strided(ctx, ids.data(), ids.size(), (const U256*)yv, nver * K, K, n, t, nver, K, (U256*)poly, status, summ,
+                                                             bad, stream));
             return;
         }
         if (grouped) {
@@ -367,14 +372,16 @@ struct RanDouSha : Producer {
         grouped = (n - t - 1) * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: room for all their results
         together = !grouped && 2 * t < n && verifiers_together(n - t - 1);
         const size_t vr = grouped || together ? n - t - 1 : 1;
-        arena((n * K * (3 * t + 2) + 5 * n * n * K + (together ? 2 * vr * n * K : 0) + K * n + (2 + 4 * vr) * K + 2 * n * nout) * f.eb + (8 + 2 * vr) * K + (1 << 14));
+        const size_t vc = together && f.gl ? vr : 1;  // Goldilocks has no selective decode: the verifiers' full interpolations, all in one call
+        arena((n * K * (3 * t + 2) + 5 * n * n * K + (together ? 2 * vr * n * K : 0) + vc * K * n + (2 * vc + 4 * vr) * K + 2 * n * nout) * f.eb +
+              (8 * vc + 2 * vr) * K + (1 << 14));
         coeffs_t = take("coeffs_t", n * K * (t + 1)), coeffs_2t = take("coeffs_2t", n * K * (2 * t + 1));
         S_t = take("S_t", n * n * K), S_2t = take("S_2t", n * n * K);
         x = take("x", n * n * K), y_t = take("y_t", n * n * K), y_2t = take("y_2t", n * n * K);
         if (together) yv_t = take("yv_t", vr * n * K), yv_2t = take("yv_2t", vr * n * K);  // [party][verifier][K]
-        poly = take("poly", K * n);  // workspace of the verifier interpolations that have no c0-only kernel
-        c0_t = take("c0_t", K), c0_2t = take("c0_2t", K);
-        deg_t = reinterpret_cast<uint32_t*>(take_bytes("deg_t", 4 * K, K)), deg_2t = reinterpret_cast<uint32_t*>(take_bytes("deg_2t", 4 * K, K));
+        poly = take("poly", vc * K * n);  // workspace of the verifier interpolations that have no c0-only kernel
+        c0_t = take("c0_t", vc * K), c0_2t = take("c0_2t", vc * K);
+        deg_t = reinterpret_cast<uint32_t*>(take_bytes("deg_t", 4 * vc * K, K)), deg_2t = reinterpret_cast<uint32_t*>(take_bytes("deg_2t", 4 * vc * K, K));
         sel_t = take("sel_t", 2 * K * vr), sel_2t = take("sel_2t", 2 * K * vr);  // (constant term, top coefficient) of a verifier's two polynomials
         st_t = take_bytes("st_t", K * vr, K), st_2t = take_bytes("st_2t", K * vr, K);
         bad = reinterpret_cast<uint32_t*>(take_bytes("bad", 64, 16));
@@ -393,6 +400,12 @@ struct RanDouSha : Producer {
         // step 3: verifiers t + 1 .. n - 1 interpolate both sharings through all n shares and test the degrees and the constant terms
         // (:586-602) -- they keep nothing else of them
         const size_t nver = n - t - 1, v0 = (t + 1) * n * K * f.eb;  // verifier i's sender rows: y + i n K
+        if (together && f.gl) {  // the n senders' rows nver K apart: every verifier's interpolation in one call, the verdicts in one
+            PL(f.interpolate_c0(ctx, ids.data(), n, yv_t, nver * K, nver * K, n, poly, c0_t, deg_t, stream));
+            PL(f.interpolate_c0(ctx, ids.data(), n, yv_2t, nver * K, nver * K, n, poly, c0_2t, deg_2t, stream));
+            PL(hbmpc_dev_check_double_share_c0_columns(ctx, c0_t, deg_t, c0_2t, deg_2t, nver * K, K, t, bad, stream));
+            return;
+        }
         if (together) {  // sender j's row: yv + j nver K, verifier i's columns at i K inside it -- groups that follow each other
             PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)yv_t, nver * K, K, n, t, nver, K, (U256*)poly, (U256*)sel_t, st_t, stream));
             PL(hbmpc_dev_interpolate_degree_check_strided(ctx, ids.data(), n, (const U256*)yv_2t, nver * K, K, n, 2 * t, nver, K, (U256*)poly, (U256*)sel_2t, st_2t,

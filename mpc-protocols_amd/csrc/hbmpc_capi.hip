@@ -1784,15 +1784,10 @@ static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x
     auto copy_lists = [&]() -> ShareErrorCode {  // every row is in y[row][G]: the list rows are copied out per slice
         if (!lists) return ShareSuccess;
         const size_t parties = G / lists->K;
-        if (lists->others) {  // and the other rows into their party-major place: per row a [parties][K] block copy
-            const size_t eb = ebytes(ctx), nother = n - lists->rows;
-            for (size_t row = 0, rp = 0; row < n; ++row) {
-                if (row >= lists->row0 && row < lists->row0 + lists->rows) continue;
-                const ShareErrorCode rc = hbmpc_memcpy_d2d_rows(ctx, (uint8_t*)lists->others + rp * lists->K * eb, nother * lists->K * eb,
-                                                                (const uint8_t*)y + row * G * eb, lists->K * eb, lists->K * eb, parties, stream);
-                if (rc != ShareSuccess) return rc;
-                ++rp;
-            }
+        if (lists->others) {  // and the other rows into their party-major place
+            launch_rows_party_major(is_gold(ctx) ? 1 : 4, (const uint64_t*)y, G, lists->K, (int)lists->row0, (int)lists->rows, (int)(n - lists->rows),
+                                    (uint64_t*)lists->others, s);
+            HIP_TRY(ctx, hipGetLastError());
         }
         for (size_t k = 0; k < lists->n_slices; ++k) {
             const hbmpc_list_slice& sl = lists->slices[k];
@@ -2010,15 +2005,23 @@ extern "C" ShareErrorCode hbmpc_dev_check_double_share(hbmpc_ctx* ctx, const voi
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
 }
-extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
-                                                          const uint32_t* degree_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream) {
+// columns: 0, or the G entries are several verifiers' results for the same `columns` columns, one verifier after the other (G a multiple of it):
+// bad[1] is then the first failing COLUMN
+extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0_columns(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
+                                                                  const uint32_t* degree_2t_dev, size_t G, size_t columns, size_t t, uint32_t* bad_dev,
+                                                                  void* stream) {
     if (!ctx) return InvalidInput;
     if (!bad_dev || (G && (!c0_t_dev || !c0_2t_dev || !degree_t_dev || !degree_2t_dev))) return fail(ctx, InvalidInput, "null buffer");
+    if (columns && G % columns != 0) return fail(ctx, InvalidInput, "G must be a multiple of the number of columns");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t s = pick(ctx, stream);
-    if (G) launch_check_double_c0(is_gold(ctx) ? 1 : 4, (const uint64_t*)c0_t_dev, degree_t_dev, (const uint64_t*)c0_2t_dev, degree_2t_dev, G, (int)t, bad_dev, s);
+    if (G) launch_check_double_c0(is_gold(ctx) ? 1 : 4, (const uint64_t*)c0_t_dev, degree_t_dev, (const uint64_t*)c0_2t_dev, degree_2t_dev, G, (int)t, bad_dev, s, columns);
     HIP_TRY(ctx, hipGetLastError());
     return ShareSuccess;
+}
+extern "C" ShareErrorCode hbmpc_dev_check_double_share_c0(hbmpc_ctx* ctx, const void* c0_t_dev, const uint32_t* degree_t_dev, const void* c0_2t_dev,
+                                                          const uint32_t* degree_2t_dev, size_t G, size_t t, uint32_t* bad_dev, void* stream) {
+    return hbmpc_dev_check_double_share_c0_columns(ctx, c0_t_dev, degree_t_dev, c0_2t_dev, degree_2t_dev, G, 0, t, bad_dev, stream);
 }
 
 #include "capi_recover.inc"

@@ -184,6 +184,17 @@ __global__ __launch_bounds__(256) void k_transpose(const uint64_t* __restrict__ 
         if (r0 + r < rows && c0 + c < cols) d[(c0 + c) * dst_row_stride + r0 + r] = tile[r][c];
     }
 }
+// The rows outside [row0, row0 + rows) of y[row][party, k] (G = parties K elements per row) party-major: row number r' among them of chunk
+// (j, k) to dst[(j nother + r') K + k] -- what the mixing kernel writes itself where it covers the shape (MfmaRowsArgs::other_stride)
+template <int W>
+__global__ __launch_bounds__(256) void k_rows_party_major(const uint64_t* __restrict__ src, size_t G, size_t K, int row0, int rows, int nother,
+                                                          uint64_t* __restrict__ dst) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= G) return;
+    const int rp = blockIdx.y, row = rp < row0 ? rp : rp + rows;
+    const size_t j = c / K, k = c - j * K;
+    reinterpret_cast<LayoutElem<W>*>(dst)[(j * nother + rp) * K + k] = reinterpret_cast<const LayoutElem<W>*>(src)[(size_t)row * G + c];
+}
 // degree (DensePolynomial::degree(): 0 for the zero polynomial) of polynomial g, coefficients at coeffs + g * stride
 template <int W>
 __device__ inline int layout_degree(const uint64_t* coeffs, int m) {
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256) void k_check_double(const uint64_t* __restrict
 template <int W>
 __global__ __launch_bounds__(256) void k_check_double_c0(const uint64_t* __restrict__ c0t, const uint32_t* __restrict__ degt,
                                                          const uint64_t* __restrict__ c02t, const uint32_t* __restrict__ deg2t, size_t G, int t,
-                                                         uint32_t* __restrict__ bad) {
+                                                         uint32_t* __restrict__ bad, size_t columns) {
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool wrong = false;
     if (g < G) {
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256) void k_check_double_c0(const uint64_t* __restr
     const unsigned long long mask = __ballot(wrong);
     if (mask != 0 && (threadIdx.x & 63) == __ffsll((long long)mask) - 1) {
         atomicAdd(bad, (uint32_t)__popcll(mask));
-        atomicMin(bad + 1, (uint32_t)g);
+        atomicMin(bad + 1, (uint32_t)(g % columns));  // several verifiers' columns in one array: the column, not the chunk
     }
 }
 // c0[g] = coeffs[g][0] of chunk-major coefficient rows (the shapes without a fused kernel)

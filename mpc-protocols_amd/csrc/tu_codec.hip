@@ -71,10 +71,16 @@ void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size
     else hipLaunchKernelGGL(k_check_double<1>, grid, dim3(256), 0, s, ct, c2t, G, m, t, bad);
 }
 void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,
-                            uint32_t* bad, hipStream_t s) {
+                            uint32_t* bad, hipStream_t s, size_t columns) {
     const dim3 grid((unsigned)((G + 255) / 256));
-    if (ew64 == 4) hipLaunchKernelGGL(k_check_double_c0<4>, grid, dim3(256), 0, s, c0t, degt, c02t, deg2t, G, t, bad);
-    else hipLaunchKernelGGL(k_check_double_c0<1>, grid, dim3(256), 0, s, c0t, degt, c02t, deg2t, G, t, bad);
+    if (columns == 0) columns = G;
+    if (ew64 == 4) hipLaunchKernelGGL(k_check_double_c0<4>, grid, dim3(256), 0, s, c0t, degt, c02t, deg2t, G, t, bad, columns);
+    else hipLaunchKernelGGL(k_check_double_c0<1>, grid, dim3(256), 0, s, c0t, degt, c02t, deg2t, G, t, bad, columns);
+}
+void launch_rows_party_major(int ew64, const uint64_t* src, size_t G, size_t K, int row0, int rows, int nother, uint64_t* dst, hipStream_t s) {
+    const dim3 grid((unsigned)((G + 255) / 256), (unsigned)nother);
+    if (ew64 == 4) hipLaunchKernelGGL(k_rows_party_major<4>, grid, dim3(256), 0, s, src, G, K, row0, rows, nother, dst);
+    else hipLaunchKernelGGL(k_rows_party_major<1>, grid, dim3(256), 0, s, src, G, K, row0, rows, nother, dst);
 }
 void launch_take_c0(int ew64, const uint64_t* coeffs, size_t G, int m, uint64_t* c0, hipStream_t s) {
     const dim3 grid((unsigned)((G + 255) / 256));

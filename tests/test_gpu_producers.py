@@ -203,6 +203,81 @@ def test_producers_at_a_size_that_takes_the_large_batch_kernels():
         eng.close()
 
 
+@pytest.mark.parametrize("field,n,t,K", [("goldilocks", 16, 5, 3000), ("goldilocks", 7, 2, 5001), ("goldilocks", 10, 3, 2500), ("fr", 10, 3, 4000),
+                                         ("fr", 4, 1, 6000), ("goldilocks", 4, 1, 6000)])
+def test_producers_at_the_batch_sizes_of_the_reference_node(field, n, t, K):
+    """Some thousands of columns per dealer (the reference node's own batches, honeybadger/mod.rs:106-120): the dealers' encodes are one
+    launch over (dealer, polynomial), the verifiers' rows are party-major and every kind of verifier is ONE decode over (verifier, column)
+    chunks (capi_pipelines.hip: Producer::verifiers_together; over Goldilocks and on 4-point domains through k_rows_party_major and the
+    full interpolations).  Sampled columns of every party's outputs against the oracle, the verdicts, tampering caught with its column."""
+    from oracle import cref as O
+    S, to_dev, to_int = _field(field)
+    gl = field != "fr"
+    pkg = load_package()
+    eng = pkg.Engine(0, field="goldilocks" if gl else "fr")
+    rng = random.Random(7 * n + K)
+    nrng = np.random.default_rng(K + n)
+    sample = sorted(set(rng.sample(range(K), 10) + [0, K - 1]))
+
+    def rand(count, shape):
+        if gl:
+            return nrng.integers(0, S.R_MOD, size=shape, dtype=np.uint64)
+        return O.fill_random(int(nrng.integers(1, 1 << 30)), count).reshape(shape + (4,))
+
+    def ints(a):  # [..] elements -> Python ints
+        return [int(x) for x in a.reshape(-1)] if gl else u256_to_ints(np.ascontiguousarray(a).reshape(-1, 4))
+
+    try:
+        co = rand(n * K * (t + 1), (n, K, t + 1))
+        rs = pkg.pipelines.RanSha(eng, n, t, K)
+        rs.upload(co)
+        rs.run(check=True)
+        got = rs.download().reshape((n, K, n - 2 * t) + ((4,) if not gl else ()))
+        pol = [[ints(co[p, k]) for k in sample] for p in range(n)]
+        want, ok = S.ransha(pol, n, t)
+        assert all(ok)
+        for j in range(n):
+            assert ints(got[j, sample]) == want[j], j
+        rs.deal()
+        k_bad, U = K - 7, rs.U
+        off = ((2 * n + 1) * K + k_bad) * U
+        cur = eng._new((1,))
+        eng.d2h(cur, rs.S + off)
+        eng.sync()
+        eng.h2d(rs.S + off, to_dev([(ints(cur)[0] + 1) % S.R_MOD]))
+        with pytest.raises(RuntimeError, match="RanSha"):
+            rs.finish(check=True)
+        assert rs._bad()[0] >= 1 and rs._bad()[1] == k_bad
+        rs.close()
+
+        ct = rand(n * K * (t + 1), (n, K, t + 1))
+        c2t = rand(n * K * (2 * t + 1), (n, K, 2 * t + 1))
+        c2t[:, :, 0] = ct[:, :, 0]
+        rd = pkg.pipelines.RanDouSha(eng, n, t, K)
+        rd.upload(ct, c2t)
+        rd.run(check=True)
+        a, b = rd.download()
+        tail = (4,) if not gl else ()
+        a, b = a.reshape((n, K, t + 1) + tail), b.reshape((n, K, t + 1) + tail)
+        want_t, want_2t, ok = S.randousha([[ints(ct[p, k]) for k in sample] for p in range(n)], [[ints(c2t[p, k]) for k in sample] for p in range(n)], n, t)
+        assert all(ok)
+        for j in range(n):
+            assert ints(a[j, sample]) == want_t[j] and ints(b[j, sample]) == want_2t[j], j
+        k_bad = K // 3
+        if gl:
+            c2t[3, k_bad, 0] ^= np.uint64(1)
+        else:
+            c2t[3, k_bad, 0, 0] ^= np.uint64(1)
+        rd.upload(ct, c2t)
+        with pytest.raises(RuntimeError, match="RanDouSha"):
+            rd.run(check=True)
+        bad, first = rd._bad()
+        assert bad == n - (t + 1) and first == k_bad
+        rd.close()
+    finally:
+        eng.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,t,K", [(16, 5, 3000), (7, 2, 9000), (13, 4, 4001)])
 def test_fused_producer_steps_write_the_same_bytes(n, t, K):

@@ -1,7 +1,8 @@
 """run_preprocessing's triple part at the batch sizes the reference's node uses (honeybadger/mod.rs:106-120, :1434: 4 096 triple groups
 per batch, i.e. N = 4 096 (2t + 1) triples per party) for the party counts of its tests and benches: device time per run, eager and as a
 HIP graph, of Preprocessing (RanSha -> a, b; DouSha + RanDouSha -> r; TripleGen) and of TripleGen alone.
-    python tools/time_protocol_sizes.py [groups]            (under rocprofv3 --kernel-trace --stats for the launches behind the times)"""
+    python tools/time_protocol_sizes.py [groups] [n,t ...]  (under rocprofv3 --kernel-trace --stats for the launches behind the times)
+    FIELD=goldilocks python tools/time_protocol_sizes.py    the reference's small field (PreprocNodesSmallField, honeybadger/mod.rs:316-324)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +10,9 @@ from __graft_entry__ import load_package
 
 pkg = load_package()
 pl = pkg.pipelines
-eng = pkg.Engine(0)
+GL = os.environ.get("FIELD", "fr") == "goldilocks"
+eng = pkg.Engine(0, field="goldilocks") if GL else pkg.Engine(0)
+EB = 8 if GL else 32
 dev = torch.device("cuda", 0)
 ts = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(ts)
@@ -19,6 +22,8 @@ shapes = [tuple(map(int, a.split(","))) for a in sys.argv[2:]] or [(4, 1), (7, 2
 
 
 def rand_fr(*shape):
+    if GL:  # canonical: below 2^63 < p
+        return torch.randint(0, 1 << 62, shape, dtype=torch.int64, device=dev)
     x = torch.randint(0, 1 << 62, shape + (4,), dtype=torch.int64, device=dev)
     x[..., 3] &= (1 << 60) - 1
     return x
@@ -48,7 +53,7 @@ for n, t in shapes:
                 co[:, 0] = sec0[p]
             elif ptr == pre.rd.coeffs_t:
                 sec0[p] = co[:, 0].clone()
-            eng.d2d(ptr + p * K * (deg + 1) * 32, co.data_ptr(), K * (deg + 1) * 32, stream)
+            eng.d2d(ptr + p * K * (deg + 1) * EB, co.data_ptr(), K * (deg + 1) * EB, stream)
             torch.cuda.synchronize()
     pre.run(check=True)
     ms_e = ev_ms(lambda: pre.run(check=False))
