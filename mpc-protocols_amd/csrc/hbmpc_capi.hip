@@ -1357,9 +1357,11 @@ static ShareErrorCode triple_encode_any(hbmpc_ctx* ctx, const void* a, const voi
     const bool small_two = tmp && G * parties <= ctx->wide_max_chunks / 4;
     // Large batches on 9 .. 32 points: the products are computed inside the matrix-core encode with the points in pairs
     // (k_mfma_bfly<.., TRIPLE>, kernels_mfma_bfly.hpp) -- config 4's 16 parties x 381 300 chunks: 2.22 - 2.28 ms against
-    // 2.53 - 2.55 of the fused FFT kernel on the same box (profiles/r03_mfma_bfly_triple.txt)
+    // 2.53 - 2.55 of the fused FFT kernel on the same box (profiles/r03_mfma_bfly_triple.txt).  From 2^14 chunks over all parties: at the
+    // reference node's batch of 4 096 chunks x 16 parties the whole TripleGen step takes 0.073 ms against 0.093 with the lane kernel, a tie
+    // at 2^14 (profiles/r04_protocol_batch_sizes.txt)
     if (ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && dp1 >= 2 && dp1 <= MF_MAX_M && size >= 16 &&
-        size <= 32 && n > size / 2 && G * parties >= ((size_t)1 << 17) && G * dp1 * 32 < ((size_t)1 << 32) && parties <= 65535) {
+        size <= 32 && n > size / 2 && G * parties >= ((size_t)1 << 14) && G * dp1 * 32 < ((size_t)1 << 32) && parties <= 65535) {
         const size_t half = size / 2;
         mf::MfmaRowsArgs ma;
         memset(&ma, 0, sizeof ma);
