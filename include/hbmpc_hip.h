@@ -402,7 +402,9 @@ ShareErrorCode hbmpc_dev_check_top_coeff(hbmpc_ctx* ctx, const void* top_dev, co
  * accumulated in bad_dev as check_double_share does.
  * groups > 1 (interpolate_degree_check) / columns > 0 (check_double_share_sel: G = groups x columns entries): several verifiers in one call,
  * verifier q's sender rows q * group_stride elements after verifier 0's and its results at sel_out_dev + q G 2, status_out_dev + q G; bad[1] is
- * the lowest failing column.  ONE launch while groups * G chunks fit the wave-per-chunk decode, a loop otherwise. */
+ * the lowest failing column.  ONE launch while groups * G chunks fit the wave-per-chunk decode, a loop otherwise -- except for groups
+ * that follow each other inside the sender rows (group_stride == G, the layout hbmpc_dev_vandermonde_apply_rows_split writes): those are
+ * one plain decode of groups * G chunks whatever the size. */
 ShareErrorCode hbmpc_dev_interpolate_degree_check_strided(hbmpc_ctx* ctx, const size_t* ids, size_t S, const U256* evals_dev, size_t row_stride,
                                                           size_t G, size_t n, size_t d, size_t groups, size_t group_stride, U256* ws_dev,
                                                           U256* sel_out_dev, uint8_t* status_out_dev, void* stream);
@@ -417,7 +419,8 @@ ShareErrorCode hbmpc_dev_check_double_share_sel(hbmpc_ctx* ctx, const void* sel_
  * coefficient only (hbmpc_dev_batch_recover_coeff_strided + hbmpc_dev_check_top_coeff); otherwise the full decode and
  * hbmpc_dev_check_degree.  Same verdict either way.
  * groups > 1: that many verifiers in one call -- verifier q's sender rows start q * group_stride elements after verifier 0's, bad[1] is the
- * lowest failing column of any of them; ONE launch while groups * G chunks fit the wave-per-chunk decode (no OEC round), a loop otherwise.
+ * lowest failing column of any of them; ONE launch while groups * G chunks fit the wave-per-chunk decode (no OEC round), a loop otherwise;
+ * groups that follow each other inside the sender rows (group_stride == G) are one plain decode of groups * G chunks at any size.
  * ws_dev: max(groups G, G (t + 1)) elements, status_out_dev: groups G bytes. */
 ShareErrorCode hbmpc_dev_recover_check_degree_strided(hbmpc_ctx* ctx, const size_t* sender_ids, size_t S, const U256* evals_dev, size_t row_stride,
                                                       size_t G, size_t n, size_t t, size_t groups, size_t group_stride, U256* ws_dev,
