@@ -234,6 +234,10 @@ struct FpMul : hbmpc_pipe {
 // sends verifier i is y[i][j K .. j K + K): a strided sender row, nothing is copied.
 struct Producer : hbmpc_pipe {
     size_t n, t, K;
+    // all verifiers' columns in ONE launch of the wave-per-chunk decode (groups): ahead of the other forms up to this many chunks -- at 6 144 and
+    // 8 192 (n = 7 at the node's 1 536 / 2 048 columns) the party-major form below takes 0.070 / 0.037 ms against 0.121 / 0.071
+    // (profiles/r04_protocol_batch_sizes.txt)
+    size_t grouped_max = 4096;
     size_t dealers_together_max = 16384;  // above: a launch per dealer (the matrix-core encode, each fills the chip)
     Producer(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : hbmpc_pipe(cx, s), n(n_), t(t_), K(K_) {}
     void deal_one(const unsigned char* coeffs, size_t deg, unsigned char* S) {
@@ -306,7 +310,7 @@ struct RanSha : Producer {
         : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
         if (verify_senders == 0) verify_senders = 2 * t + 1;
         if (verify_senders < 2 * t + 1 || verify_senders > n) throw PipeError{InvalidInput};
-        grouped = 2 * t * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: workspace for all of them
+        grouped = 2 * t * K <= grouped_max;  // the verifiers' columns fit one launch of the wave-per-chunk decode: workspace for all of them
         together = !grouped && verify_senders == 2 * t + 1 && verifiers_together(2 * t);
         const bool all = grouped || together;
         const size_t poly_el = K * (all && 2 * t > t + 1 ? 2 * t : t + 1), status_b = all ? 2 * t * K + 1 : K;
@@ -369,7 +373,7 @@ struct RanDouSha : Producer {
         return (t + 1) * K;
     }
     RanDouSha(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : Producer(cx, n_, t_, K_, s), nout(checked_nout(n_, t_, K_)) {
-        grouped = (n - t - 1) * K <= 8192;  // the verifiers' columns fit one launch of the wave-per-chunk decode: room for all their results
+        grouped = (n - t - 1) * K <= grouped_max && !f.gl;  // (Fr only) the verifiers' columns fit one launch of the wave-per-chunk decode: room for all their results
         together = !grouped && 2 * t < n && verifiers_together(n - t - 1);
         const size_t vr = grouped || together ? n - t - 1 : 1;
         const size_t vc = together && f.gl ? vr : 1;  // Goldilocks has no selective decode: the verifiers' full interpolations, all in one call

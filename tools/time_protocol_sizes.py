@@ -65,3 +65,24 @@ for n, t in shapes:
     print(f"n={n:2d} t={t} N={N:6d} K_rs={pre.K_rs:6d} K_rd={pre.K_rd:6d}: preprocessing {ms_e:.3f} ms eager, {ms_g:.3f} ms graph "
           f"({N / ms_g * 1e3:.3e} triples/s); RanSha {ms_rs:.3f}  RanDouSha {ms_rd:.3f}  TripleGen {ms_tg:.3f}", flush=True)
     pre.close()
+
+
+# the producers alone at the column counts the reference's node hard-codes per run: RanSha 2 048 (honeybadger/mod.rs:1434), RanDouSha 1 536 (:114-120)
+for n, t in shapes:
+    rs = pl.RanSha(eng, n, t, 2048, stream)
+    rd = pl.RanDouSha(eng, n, t, 1536, stream)
+    for p in range(n):
+        co = rand_fr(2048, t + 1)
+        eng.d2d(rs.coeffs + p * 2048 * (t + 1) * EB, co.data_ptr(), 2048 * (t + 1) * EB, stream)
+        ct, c2t = rand_fr(1536, t + 1), rand_fr(1536, 2 * t + 1)
+        c2t[:, 0] = ct[:, 0]
+        eng.d2d(rd.coeffs_t + p * 1536 * (t + 1) * EB, ct.data_ptr(), 1536 * (t + 1) * EB, stream)
+        eng.d2d(rd.coeffs_2t + p * 1536 * (2 * t + 1) * EB, c2t.data_ptr(), 1536 * (2 * t + 1) * EB, stream)
+        torch.cuda.synchronize()
+    rs.run(check=True)
+    rd.run(check=True)
+    ms_rs, ms_rd = ev_ms(lambda: rs.run(check=False)), ev_ms(lambda: rd.run(check=False))
+    rs.capture(), rd.capture()
+    print(f"n={n:2d} t={t}: RanSha 2048 columns {ms_rs:.3f} ms eager, {ev_ms(rs.replay):.3f} graph ({(n - 2 * t) * 2048 / ms_rs * 1e3:.3e} sharings/s per party); "
+          f"RanDouSha 1536 columns {ms_rd:.3f} ms eager, {ev_ms(rd.replay):.3f} graph", flush=True)
+    rs.close(), rd.close()
