@@ -204,7 +204,8 @@ def test_producers_at_a_size_that_takes_the_large_batch_kernels():
 
 
 @pytest.mark.parametrize("field,n,t,K", [("goldilocks", 16, 5, 3000), ("goldilocks", 7, 2, 5001), ("goldilocks", 10, 3, 2500), ("fr", 10, 3, 4000),
-                                         ("fr", 4, 1, 6000), ("goldilocks", 4, 1, 6000)])
+                                         ("fr", 4, 1, 6000), ("goldilocks", 4, 1, 6000),
+                                         ("fr", 7, 2, 2048), ("goldilocks", 7, 2, 1536), ("fr", 16, 5, 1536)])   # the node's column counts per run
 def test_producers_at_the_batch_sizes_of_the_reference_node(field, n, t, K):
     """Some thousands of columns per dealer (the reference node's own batches, honeybadger/mod.rs:106-120): the dealers' encodes are one
     launch over (dealer, polynomial), the verifiers' rows are party-major and every kind of verifier is ONE decode over (verifier, column)
