@@ -140,7 +140,10 @@ def test_full_size_config2(eng):
 
 
 @pytest.mark.parametrize("n,t,G,parties", [(16, 5, 9000 + 7, 16), (16, 5, 140000, 1), (13, 4, 50000 + 3, 3), (16, 2, 70000, 2), (16, 7, 33000 + 1, 4),
-                                           (20, 3, 44000 + 5, 3), (24, 4, 66000, 2), (9, 1, 131072, 1)])
+                                           (20, 3, 44000 + 5, 3), (24, 4, 66000, 2), (9, 1, 131072, 1),
+                                           # from 2^14 chunks over all parties (the reference node's batches: 4 096 chunks x n parties)
+                                           (16, 5, 1100, 16), (16, 5, 4096 + 3, 16), (13, 4, 6000 + 1, 3), (10, 3, 20000, 1), (16, 5, 1024, 16), (16, 5, 1000, 16),
+                                           (20, 3, 5000 + 9, 4)])
 def test_triple_generation_encode_with_the_products_inside(eng, n, t, G, parties):
     """hbmpc_dev_triple_encode_parties on large batches: the local products a b - r2t are computed inside the matrix-core encode
     (k_mfma_bfly<.., TRIPLE>).  Against hbmpc_dev_triple_local + hbmpc_dev_vandermonde_apply_parties with the matrix cores off
