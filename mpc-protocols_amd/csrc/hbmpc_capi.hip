@@ -673,6 +673,14 @@ struct ListSpec {
     size_t n_slices;
     void* others = nullptr;  // non-null: the rows outside the lists go here, party-major: others[(j (n - rows) + r') K + k] (hbmpc_dev_vandermonde_apply_rows_split)
 };
+// x[P][G][M] -> y[P][n][G] as ONE launch of the point-pair kernel over the P G chunks (k_mfma_bfly<.., LISTS> with every row party-major,
+// tu_mfma_bfly.inc: launch_lists): domains of 8 and 16 points, M <= 11, dense output rows, enough tiles over all parties to fill the chip
+static bool party_batched_one_launch(const hbmpc_ctx* ctx, size_t G, size_t n, size_t dp1, const EvalOut& y) {
+    const size_t size = domain_size(n);
+    return y.parties > 1 && y.ys == 0 && ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && size >= 8 && size <= 16 &&
+           n > size / 2 && dp1 >= 2 && dp1 <= 11 && ((size_t)y.parties * G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
+           (size_t)y.parties * n * G * 32 < ((size_t)1 << 32) && (size_t)y.parties * G * dp1 * 32 < ((size_t)1 << 32);
+}
 static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n, size_t dp1, EvalOut y, hipStream_t s,
                           ShareErrorCode* rc_out, size_t x_row_stride = 0, const ListSpec* lists = nullptr) {
     *rc_out = ShareSuccess;
@@ -683,7 +691,9 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
     const int nwg = ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus;
     // (measured, 4 096 .. 16 384 chunks: n = 20, d = 6: 6.7 .. 10.0 us against 19 .. 20; n = 31, d = 10 -- three roles --
     // 9.8 and 15.1 us against 17.6 and 18.2 at 4 096 and 8 192 chunks, behind at 16 384)
-    bool team = ctx->mfma_team && x_row_stride == 0 && dp1 <= MF_MAX_M && (G + 31) / 32 <= (size_t)nwg * 2;
+    // several parties' encodes in one launch (below): the tiles of all of them count
+    const bool parties_one = party_batched_one_launch(ctx, G, n, dp1, y) && !lists && !x_row_stride;
+    bool team = ctx->mfma_team && x_row_stride == 0 && dp1 <= MF_MAX_M && (G + 31) / 32 <= (size_t)nwg * 2 && !parties_one;
     bool plain_ok = x_row_stride == 0 && dp1 <= MF_MAX_M && mf::mf_plan_roles((int)n, 0, (int)((160 * 1024 - (team ? 128 : 0)) / rowb), nwg, &a);
     if (plain_ok && team && a.nroles > 1 && (G + 31) / 32 > (size_t)nwg) {
         team = false;
@@ -740,6 +750,17 @@ static bool try_mfma_eval(hbmpc_ctx* ctx, const uint32_t* x, size_t G, size_t n,
                     b.list[k].k0 = have ? (uint32_t)lists->slices[k].k0 : 0u;
                     b.list[k].count = have ? (uint32_t)lists->slices[k].count : 0u;
                 }
+            }
+            // party-batched calls x[P][G][M] -> y[P][n][G]: ONE launch over the P G chunks where the instance with party-major "other" rows
+            // covers the shape (MfmaRowsArgs::other_stride with no list rows: chunk (p, g) of row k goes to ((p n + k) G + g)) -- the
+            // dealers' encodes of the producers; otherwise a launch per party
+            if (parties_one && b.nroles == 1 && (b.role[0].nrows == 4 || b.role[0].nrows == 8)) {
+                mf::MfmaRowsArgs pb = b;  // the plan does not depend on the number of chunks (workgroups stride over the tiles)
+                pb.G = (size_t)y.parties * G, pb.list_K = (uint32_t)G, pb.other_stride = (uint32_t)(n * G), pb.list_row0 = 0, pb.list_rows = 0;
+                pb.in = (const uint8_t*)x, pb.out = (uint8_t*)y.y;
+                if (launch_mfma_bfly_a(mi, pb, ctx->device, s) || launch_mfma_bfly_b(mi, pb, ctx->device, s) || launch_mfma_bfly_c(mi, pb, ctx->device, s) ||
+                    launch_mfma_bfly_d(mi, pb, ctx->device, s))
+                    return true;
             }
             for (unsigned p = 0; p < y.parties && ok; ++p) {  // party-batched calls: one launch per party
                 b.in = (const uint8_t*)x + (size_t)p * G * dp1 * 32;
@@ -854,6 +875,8 @@ static ShareErrorCode eval_impl(hbmpc_ctx* ctx, const uint32_t* x, size_t G, siz
         dp1 >= 2 && dp1 <= MF_BFLY_MAX_M && (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 &&
         G * std::max(dp1, (size_t)1) * 32 < ((size_t)1 << 32) && try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf))
         return rc_mf;
+    // several parties' mid-size batches: one launch over all of them (the dealers' encodes of the producers)
+    if (party_batched_one_launch(ctx, G, n, dp1, y) && try_mfma_eval(ctx, x, G, n, dp1, y, s, &rc_mf)) return rc_mf;
     if ((impl == IMPL_U29 || gold) && size <= 16 && !ctx->force_generic) {
         const uint32_t* tw;
         ShareErrorCode rc = get_table(ctx, key("tw", {size}, impl), [&] {

@@ -209,6 +209,33 @@ def test_inputs_given_as_rows(eng, n, d, G):
         assert rc != 0 and "workspace" in eng.last_error()
 
 
+@pytest.mark.parametrize("n,d,G,parties", [(16, 5, 1100, 16), (16, 10, 1536 + 3, 16), (7, 2, 2048 + 1, 7), (10, 3, 4000, 10), (13, 8, 7000 + 5, 3), (16, 5, 15019, 16),
+                                           (5, 1, 9000, 5), (16, 5, 20000 + 1, 2), (16, 5, 130, 16), (16, 11, 3000, 16), (20, 6, 3000, 8), (4, 1, 6000, 4)])
+def test_party_batched_encode_is_one_launch_with_the_same_bytes(eng, n, d, G, parties):
+    """hbmpc_dev_vandermonde_apply_parties, x[P][G][d + 1] -> y[P][n][G] (the dealers' compute_shares of the producers): where the point-pair
+    kernel covers the shape all parties' chunks are ONE launch (k_mfma_bfly<.., LISTS> with every row party-major) -- against the lane
+    kernels (matrix cores off: the whole array) and the oracle on the first and the last party; shapes outside it (d + 1 > 11, 4- and 32-point
+    domains, few chunks) take the other paths and must agree as well"""
+    import torch
+    dev = torch.device("cuda", 0)
+    x = polys(5 * n + d + G, parties * G, d)
+    xd = torch.as_tensor(x.view(np.int64), device=dev)
+    y1 = torch.full((parties, n, G, 4), -1, dtype=torch.int64, device=dev)
+    y2 = torch.full((parties, n, G, 4), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_vandermonde_apply_parties(xd.data_ptr(), G, n, d, parties, y1.data_ptr()) == 0, eng.last_error()
+    eng.set_matrix_cores(0)
+    try:
+        assert eng.dev_vandermonde_apply_parties(xd.data_ptr(), G, n, d, parties, y2.data_ptr()) == 0, eng.last_error()
+        eng.sync()
+    finally:
+        eng.set_matrix_cores(1, 65536)
+    assert torch.equal(y1, y2)
+    for p in (0, parties - 1):
+        rc, want = O.vandermonde_apply(x[p * G:(p + 1) * G], n, d)
+        assert rc == 0 and np.array_equal(y1[p].cpu().numpy().view(np.uint64), want), p
+
+
 @pytest.mark.parametrize("n,K,row0,rows", [(16, 1500, 10, 6), (16, 1237, 0, 6), (7, 3001, 4, 3), (13, 2000, 0, 5), (4, 5000, 2, 2), (16, 40, 10, 6),
                                            (16, 1500, 0, 15), (16, 1500, 15, 1)])
 def test_mixing_step_with_lists_and_party_major_other_rows(eng, n, K, row0, rows):
