@@ -243,8 +243,8 @@ struct Producer : hbmpc_pipe {
     void deal_one(const unsigned char* coeffs, size_t deg, unsigned char* S) {
         // compute_shares of every dealer's K polynomials: coeffs [dealer][K][deg + 1] -> S [dealer][recipient][K] is the party-batched
         // encode's layout.  A launch per dealer fills the chip only from some tens of thousands of polynomials; below that the dealers go
-        // together: up to 2 048 chunks per call through the wave-per-chunk kernels, a mid-size batch in ONE launch of the lane-per-polynomial
-        // kernels over (dealer, polynomial) -- at the reference's own batch sizes (K ~ 7 000 .. 15 000, n = 16) 16 launches of 10 us each
+        // together: up to 2 048 chunks per call through the wave-per-chunk kernels, a mid-size batch in ONE launch over (dealer, polynomial)
+        // (hbmpc_dev_vandermonde_apply_parties: the point-pair matrix-core kernel on domains of 8 / 16 points, the lane kernels elsewhere) -- at the reference's own batch sizes (K ~ 7 000 .. 15 000, n = 16) 16 launches of 10 us each
         // were 45 % of the producers' time (profiles/r04_protocol_batch_sizes.txt)
         auto together = [&](size_t p, size_t cnt) {
             const unsigned char* co = coeffs + p * K * (deg + 1) * f.eb;
