@@ -238,11 +238,14 @@ struct Producer : hbmpc_pipe {
     // 8 192 (n = 7 at the node's 1 536 / 2 048 columns) the party-major form below takes 0.070 / 0.037 ms against 0.121 / 0.071
     // (profiles/r04_protocol_batch_sizes.txt)
     size_t grouped_max = 4096;
-    size_t dealers_together_max = 16384;  // above: a launch per dealer (the matrix-core encode, each fills the chip)
+    // above: a launch per dealer.  Measured (tools/time_dealers_together.py, n = 16, degree 5): 0.037 ms against 0.146 at 16 000 polynomials per
+    // dealer, 0.159 / 0.295 at 65 536, 0.613 / 0.787 at 262 144 -- a launch of one dealer's batch spends a visible part of its time filling and
+    // draining the chip until the batch has some 10^6 polynomials
+    size_t dealers_together_max = ((size_t)1 << 20) - 1;
     Producer(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : hbmpc_pipe(cx, s), n(n_), t(t_), K(K_) {}
     void deal_one(const unsigned char* coeffs, size_t deg, unsigned char* S) {
         // compute_shares of every dealer's K polynomials: coeffs [dealer][K][deg + 1] -> S [dealer][recipient][K] is the party-batched
-        // encode's layout.  A launch per dealer fills the chip only from some tens of thousands of polynomials; below that the dealers go
+        // encode's layout.  A launch per dealer is at the memory rate only from some 10^6 polynomials; below that the dealers go
         // together: up to 2 048 chunks per call through the wave-per-chunk kernels, a mid-size batch in ONE launch over (dealer, polynomial)
         // (hbmpc_dev_vandermonde_apply_parties: the point-pair matrix-core kernel on domains of 8 / 16 points, the lane kernels elsewhere) -- at the reference's own batch sizes (K ~ 7 000 .. 15 000, n = 16) 16 launches of 10 us each
         // were 45 % of the producers' time (profiles/r04_protocol_batch_sizes.txt)
@@ -257,9 +260,13 @@ struct Producer : hbmpc_pipe {
             for (size_t p = 0; p < n; p += per) together(p, n - p < per ? n - p : per);
             return;
         }
-        if (K <= dealers_together_max) {
-            together(0, n);
-            return;
+        if (K <= dealers_together_max) {  // as many dealers per call as the one-launch form's 32-bit offsets allow (4 GiB of outputs, of inputs)
+            const size_t lim = ((size_t)1 << 32) - 1;
+            const size_t per = std::min(n, std::min(lim / (n * K * f.eb), lim / (K * (deg + 1) * f.eb)));
+            if (per >= 2) {
+                for (size_t p = 0; p < n; p += per) together(p, n - p < per ? n - p : per);
+                return;
+            }
         }
         for (size_t p = 0; p < n; ++p)  // dealer p: compute_shares of its K polynomials
             PL(f.compute_shares(ctx, coeffs + p * K * (deg + 1) * f.eb, K, n, deg, S + p * n * K * f.eb, stream));

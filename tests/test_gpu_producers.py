@@ -141,14 +141,15 @@ def test_preprocessing_chain_from_dealers_to_triples(n, t, groups):             
         eng.close()
 
 
-def test_producers_at_a_size_that_takes_the_large_batch_kernels():
-    """K = 20 000 batch elements per dealer, n = 16: the dealers' encodes, the n x n mixing step over the dealt rows
+@pytest.mark.parametrize("K", [20000, 70000])   # 70 000: a launch per verifier (from 2^16 columns), the dealers still in one launch
+def test_producers_at_a_size_that_takes_the_large_batch_kernels(K):
+    """K = 20 000 (70 000) batch elements per dealer, n = 16: the dealers' encodes, the n x n mixing step over the dealt rows
     (hbmpc_dev_vandermonde_apply_rows, d + 1 = 16) and the RanDouSha verifiers' full-domain interpolation with its degrees all run
     on the point-pair matrix-core kernel here (the small cases above stay below its thresholds).  Every party's outputs for sampled
     batch elements against the oracle, the verifiers' verdicts, and a tampered share caught at this size too."""
     from oracle import cref as O
     S = SFR
-    n, t, K = 16, 5, 20000
+    n, t = 16, 5
     pkg = load_package()
     eng = pkg.Engine(0)
     rng = random.Random(99)
