@@ -141,7 +141,7 @@ def test_preprocessing_chain_from_dealers_to_triples(n, t, groups):             
         eng.close()
 
 
-@pytest.mark.parametrize("K", [20000, 70000])   # 70 000: a launch per verifier (from 2^16 columns), the dealers still in one launch
+@pytest.mark.parametrize("K", [20000, 70000])   # 70 000: beyond the lane kernels' and the team kernels' ranges, dealers and verifiers still together
 def test_producers_at_a_size_that_takes_the_large_batch_kernels(K):
     """K = 20 000 (70 000) batch elements per dealer, n = 16: the dealers' encodes, the n x n mixing step over the dealt rows
     (hbmpc_dev_vandermonde_apply_rows, d + 1 = 16) and the RanDouSha verifiers' full-domain interpolation with its degrees all run
