@@ -39,7 +39,9 @@ constexpr int MF_BFLY_BIAS = 256;
 // degree -- the index of the highest nonzero coefficient, 0 for the zero polynomial (DensePolynomial::degree(), what the
 // RanDouSha verifier tests, ran_dou_sha/mod.rs:586-589) -- so the coefficients are not read a second time for it; with
 // a.store_rows = 1 only c_0 is stored (the verifier's other test compares the constant terms of its two polynomials).
-// LISTS: the producers' mixing step with the parties' output rows written in list order (MfmaRowsArgs::list).
+// LISTS: the producers' mixing step with the parties' output rows written in list order (MfmaRowsArgs::list) and, with other_stride, the rows
+// the verifiers receive party-major ([party][verifier][k]: one decode serves all verifiers of a kind).  With no list rows at all the same
+// instance is the party-batched encode x[P][G][M] -> y[P][n][G] in one launch (list_K = G, other_stride = n G: the dealers' compute_shares).
 template <int M, int WAVES, int NP = 0, bool TRIPLE = false, int TRIPLE_DEPTH = 1, bool DEG = false, bool LISTS = false>
 __global__ __launch_bounds__(64 * WAVES) void k_mfma_bfly(MfmaRowsArgs a) {
     static_assert(M >= 2 && M <= 16, "digit sums must stay below 0xff0000 (tables_mfma.hpp: proved per table for M = 16)");
