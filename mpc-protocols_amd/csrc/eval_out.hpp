@@ -12,4 +12,16 @@ struct EvalOut {
     unsigned parties;  // independent [G][d+1] -> [n][G] problems of the launch (blockIdx.y)
 };
 
+// where the producers' mixing step writes (kernels_eval.hpp: k_eval_fft1_mix)
+struct MixOut {
+    uint32_t *y, *others;  // y[row][G] (others == nullptr) or the party-major block
+    size_t K;
+    int row0, rows;
+    struct Slice {
+        uint32_t* dst;
+        size_t stride;  // elements between the lists of consecutive parties
+        size_t k0, count;
+    } list[2];
+};
+
 }  // namespace hbmpc

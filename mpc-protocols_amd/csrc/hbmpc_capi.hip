@@ -1806,6 +1806,22 @@ static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x
         HIP_TRY(ctx, hipGetLastError());
         return ShareSuccess;
     }
+    // Goldilocks, n inputs as rows, a domain of 4 .. 16 points: the single-pass lane kernel reads the rows in place and writes the lists and the
+    // party-major rows itself (k_eval_fft1_mix) -- one launch instead of a transpose either side of the encode
+    if (lists && is_gold(ctx) && ctx->list_rows_in_kernel && !ctx->force_generic && dp1 == n && size <= 16 && n >= 3) {
+        const uint32_t* tw;
+        const ShareErrorCode rc = get_table(ctx, key("tw", {size}, ctx->impl), [&] { return build_twiddles<HGl>(size, ctx->impl); }, &tw);
+        if (rc != ShareSuccess) return rc;
+        MixOut o;
+        memset(&o, 0, sizeof o);
+        o.y = (uint32_t*)y, o.others = (uint32_t*)lists->others, o.K = lists->K, o.row0 = (int)lists->row0, o.rows = (int)lists->rows;
+        for (size_t k = 0; k < lists->n_slices; ++k)
+            o.list[k] = MixOut::Slice{(uint32_t*)lists->slices[k].dst_dev, lists->slices[k].party_stride, lists->slices[k].k0, lists->slices[k].count};
+        if (launch_gold_fft1_mix(ilog2(size), (int)dp1, (const uint32_t*)x_rows, x_row_stride, G, (int)n, tw, o, s)) {
+            HIP_TRY(ctx, hipGetLastError());
+            return ShareSuccess;
+        }
+    }
     auto copy_lists = [&]() -> ShareErrorCode {  // every row is in y[row][G]: the list rows are copied out per slice
         if (!lists) return ShareSuccess;
         const size_t parties = G / lists->K;
@@ -1855,6 +1871,10 @@ static ShareErrorCode eval_rows_lists_any(hbmpc_ctx* ctx, const void* x_rows, si
 extern "C" ShareErrorCode hbmpc_dev_apply_rows_lists_in_kernel(hbmpc_ctx* ctx, size_t G, size_t n, size_t d, int* yes_out) {
     if (!ctx || !yes_out) return InvalidInput;
     const size_t size = domain_size(n), dp1 = d + 1;
+    if (is_gold(ctx)) {  // k_eval_fft1_mix: the n x n mixing step on domains of up to 16 points, any batch size
+        *yes_out = ctx->list_rows_in_kernel && !ctx->force_generic && dp1 == n && size <= 16 && n >= 3;
+        return ShareSuccess;
+    }
     *yes_out = ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && ctx->list_rows_in_kernel && dp1 >= 2 &&
                dp1 >= 5 && dp1 <= MF_BFLY_MAX_M && size >= 8 && size <= 16 && n > size / 2 &&  // tu_mfma_bfly.inc: launch_lists
                (G + 31) / 32 > (size_t)(ctx->mfma_wgs ? ctx->mfma_wgs : ctx->n_cus) * 2 && G * 32 < ((size_t)1 << 32);

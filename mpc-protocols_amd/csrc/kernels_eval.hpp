@@ -19,6 +19,7 @@
 // stored as soon as the last stage produces it.  The same templates are instantiated for the
 // Goldilocks field (fr_gold.hpp, 8-byte elements: F::EW = 2).
 #pragma once
+#include "eval_out.hpp"
 #include <type_traits>
 #include <utility>
 
@@ -278,6 +279,52 @@ __global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::te
     fft_pruned_sink<F, LOG, CNT, 1, 1>(X, tw, [&](auto idx, const E& v) {
         constexpr int j = decltype(idx)::value;
         if (j < n) F::store_loose(y + ((size_t)j * ys + g) * F::EW, v);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// The producers' n x n mixing step in ONE launch of the single-pass kernel (share_gen.rs:401-418, ran_dou_sha/mod.rs:392-403): a lane per
+// chunk (party j, batch element k) = g / K, g % K reads its CNT = n inputs from the ROWS they were dealt into (row i at x + i * xs: for a
+// lane-per-chunk kernel the rows are the coalesced side), and writes output rows [row0, row0 + rows) into the parties' lists
+// ([k][row], up to two slices) and every other row either to y[row][G] or, with `others`, party-major to others[(j nother + r') K + k]
+// -- what hbmpc_dev_vandermonde_apply_rows_lists / _split do with a transpose either side where no kernel reads rows (Goldilocks).
+// ---------------------------------------------------------------------------------------------
+template <class F, int LOG, int CNT, int P>
+HB_DEV void load_rows_one(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ mine, size_t row_words) {
+    constexpr int k = bitrev_c(LOG, P);
+    if constexpr (k < CNT) X[P] = F::load(mine + (size_t)k * row_words);
+}
+template <class F, int LOG, int CNT, int... P>
+HB_DEV void load_rows(typename F::E (&X)[1 << LOG], const uint32_t* __restrict__ mine, size_t row_words, std::integer_sequence<int, P...>) {
+    (load_rows_one<F, LOG, CNT, P>(X, mine, row_words), ...);
+}
+template <class F, int LOG, int CNT>
+__global__ __launch_bounds__(EVAL_TILE) __attribute__((amdgpu_waves_per_eu(F::template eval_waves_min<LOG, CNT>(), F::template eval_waves<LOG, CNT>()))) void k_eval_fft1_mix(
+    const uint32_t* __restrict__ x, size_t xs, size_t G, int n, const uint32_t* __restrict__ tw, MixOut o) {
+    using E = typename F::E;
+    constexpr int S = 1 << LOG, EW = F::EW;
+    static_assert(CNT <= S && fft_max_vb<LOG, CNT, 1, 1>() <= 64, "bounds");
+    const size_t g = (size_t)blockIdx.x * EVAL_TILE + threadIdx.x;
+    if (g >= G) return;
+    E X[S];
+    load_rows<F, LOG, CNT>(X, x + g * EW, xs * EW, std::make_integer_sequence<int, S>{});
+    const size_t j = g / o.K, k = g - j * o.K;
+    uint32_t* lrow = nullptr;  // row row0 of this chunk in its party's list (nullptr: no slice holds batch element k)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (o.list[q].dst && k - o.list[q].k0 < o.list[q].count) lrow = o.list[q].dst + ((j * o.list[q].stride + (k - o.list[q].k0) * (size_t)o.rows)) * EW;
+    const int nother = n - o.rows;
+    fft_pruned_sink<F, LOG, CNT, 1, 1>(X, tw, [&](auto idx, const E& v) {
+        constexpr int r = decltype(idx)::value;
+        if (r >= n) return;
+        if (r >= o.row0 && r < o.row0 + o.rows) {
+            if (lrow) F::store_loose(lrow + (size_t)(r - o.row0) * EW, v);
+        } else if (o.others) {
+            const int rp = r < o.row0 ? r : r - o.rows;
+            F::store_loose(o.others + ((j * (size_t)nother + rp) * o.K + k) * EW, v);
+        } else {
+            F::store_loose(o.y + ((size_t)r * G + g) * EW, v);
+        }
     });
 }
 

@@ -461,6 +461,61 @@ def test_small_field_triple_encode_fused_equals_two_launches(_eng, n, t, G, part
         assert torch.equal(y3, y1)
 
 
+@pytest.mark.parametrize("n,K,row0,rows", [(16, 1500, 10, 6), (16, 37, 0, 6), (7, 3001, 4, 3), (13, 200, 0, 5), (4, 5000, 2, 2), (3, 100, 1, 2), (16, 1500, 0, 15),
+                                           (16, 700, 15, 1), (9, 65, 3, 4), (20, 300, 12, 8)])
+def test_small_field_mixing_step_in_one_launch(_eng, n, K, row0, rows):
+    """The producers' n x n mixing step over Goldilocks: hbmpc_gl_dev_vandermonde_apply_rows_split and _lists from the kernel that reads the
+    dealt rows in place and writes the parties' lists and the party-major rows itself (k_eval_fft1_mix, domains of up to 16 points)
+    against the separate passes (hbmpc_set_producer_fusion(0): transpose, encode, transposes / copies) and against the plain y[row][G],
+    itself checked against the oracle; n = 20 (a 32-point domain) has no such kernel and takes the passes either way"""
+    import ctypes as C
+    import torch
+    eng = _eng
+    dev = torch.device("cuda", 0)
+    G, d = n * K, n - 1
+    x = rnd(1000 * n + K, G, d + 1)
+    x[0] = 0
+    x[1] = P - 1
+    xr = torch.as_tensor(np.ascontiguousarray(x.T).view(np.int64), device=dev)          # rows: [d + 1][G]
+    tmp = torch.empty((G, d + 1), dtype=torch.int64, device=dev)
+    y = torch.full((n, G), -1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    assert eng.dev_vandermonde_apply_rows(xr.data_ptr(), G, G, n, d, tmp.data_ptr(), y.data_ptr()) == 0, eng.last_error()
+    eng.sync()
+    y_np = y.cpu().numpy().view(np.uint64)
+    V = np.array(S.make_vandermonde(n, d), dtype=object)                                   # oracle on the first and the last chunks
+    for sl in (slice(0, 40), slice(G - 40, G)):
+        assert np.array_equal(y_np[:, sl].astype(object), V.dot(x[sl].astype(object).T) % P)
+    other_rows = [r for r in range(n) if not row0 <= r < row0 + rows]
+    want_others = y_np.reshape(n, n, K)[other_rows].transpose(1, 0, 2)                      # [party][r'][K]
+    want_lists = y_np.reshape(n, n, K)[row0:row0 + rows].transpose(1, 2, 0)                  # [party][K][row]
+    k1 = K // 3
+    assert eng.apply_rows_lists_in_kernel(G, n, d) == (3 <= n <= 16)
+    try:
+        for fused in (1, 0):
+            assert eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(fused)) == 0
+            for with_others in (True, False):
+                la = torch.full((n, k1, rows), -1, dtype=torch.int64, device=dev)
+                lb = torch.full((n, K - k1 - 1 + 2, rows), -1, dtype=torch.int64, device=dev)
+                others = torch.full((n, n - rows, K), -1, dtype=torch.int64, device=dev)
+                y.fill_(-1)
+                torch.cuda.synchronize()
+                slices = [(la.data_ptr(), k1 * rows, 0, k1), (lb.data_ptr(), (K - k1 + 1) * rows, k1 + 1, K - k1 - 1)]
+                rc = eng.dev_vandermonde_apply_rows_split(xr.data_ptr(), G, G, n, d, tmp.data_ptr(), y.data_ptr(), row0, rows, K, slices,
+                                                          others.data_ptr() if with_others else None)
+                assert rc == 0, eng.last_error()
+                eng.sync()
+                if with_others:
+                    assert np.array_equal(others.cpu().numpy().view(np.uint64), want_others), fused
+                else:
+                    assert np.array_equal(y.cpu().numpy().view(np.uint64)[other_rows], y_np[other_rows]), fused
+                assert np.array_equal(la.cpu().numpy().view(np.uint64), want_lists[:, :k1]), fused
+                got_b = lb.cpu().numpy().view(np.uint64)
+                assert np.array_equal(got_b[:, :K - k1 - 1], want_lists[:, k1 + 1:]) and np.all(got_b[:, K - k1 - 1:] == np.uint64(2**64 - 1)), fused
+    finally:
+        eng.L.hbmpc_set_producer_fusion(eng.ctx, C.c_int(1))
+
+
 @pytest.mark.parametrize("n,t,d,G", [(16, 5, 5, 1 << 15), (16, 5, 10, 20011), (31, 10, 10, 1 << 14), (64, 21, 21, 4099)])
 def test_against_the_c_restatement_at_size(_eng, n, t, d, G):
     """hbmpc_gl_* against oracle/hbmpc_oracle.c built for Goldilocks (oracle/cref_gl.py) -- the second, independent
