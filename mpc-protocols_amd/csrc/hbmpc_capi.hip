@@ -1808,16 +1808,21 @@ static ShareErrorCode eval_rows_any(hbmpc_ctx* ctx, const void* x_rows, size_t x
     }
     // Goldilocks, n inputs as rows, a domain of 4 .. 16 points: the single-pass lane kernel reads the rows in place and writes the lists and the
     // party-major rows itself (k_eval_fft1_mix) -- one launch instead of a transpose either side of the encode
-    if (lists && is_gold(ctx) && ctx->list_rows_in_kernel && !ctx->force_generic && dp1 == n && size <= 16 && n >= 3) {
+    // (over Fr the same kernel on domains of 4 and 8 points -- 3 .. 8 parties -- where the matrix-core list kernel above did not take the call)
+    const bool mix_gl = is_gold(ctx) && size <= 16, mix_fr = ctx->impl == IMPL_U29 && size <= 8;
+    if (lists && (mix_gl || mix_fr) && ctx->list_rows_in_kernel && !ctx->force_generic && dp1 == n && n >= 3) {
         const uint32_t* tw;
-        const ShareErrorCode rc = get_table(ctx, key("tw", {size}, ctx->impl), [&] { return build_twiddles<HGl>(size, ctx->impl); }, &tw);
+        const ShareErrorCode rc = get_table(ctx, key("tw", {size}, ctx->impl), [&] {
+            return mix_gl ? build_twiddles<HGl>(size, ctx->impl) : build_twiddles<HFr>(size, ctx->impl);
+        }, &tw);
         if (rc != ShareSuccess) return rc;
         MixOut o;
         memset(&o, 0, sizeof o);
         o.y = (uint32_t*)y, o.others = (uint32_t*)lists->others, o.K = lists->K, o.row0 = (int)lists->row0, o.rows = (int)lists->rows;
         for (size_t k = 0; k < lists->n_slices; ++k)
             o.list[k] = MixOut::Slice{(uint32_t*)lists->slices[k].dst_dev, lists->slices[k].party_stride, lists->slices[k].k0, lists->slices[k].count};
-        if (launch_gold_fft1_mix(ilog2(size), (int)dp1, (const uint32_t*)x_rows, x_row_stride, G, (int)n, tw, o, s)) {
+        if (mix_gl ? launch_gold_fft1_mix(ilog2(size), (int)dp1, (const uint32_t*)x_rows, x_row_stride, G, (int)n, tw, o, s)
+                   : launch_fft1_mix_lo(ilog2(size), (int)dp1, (const uint32_t*)x_rows, x_row_stride, G, (int)n, tw, o, s)) {
             HIP_TRY(ctx, hipGetLastError());
             return ShareSuccess;
         }
@@ -1873,6 +1878,10 @@ extern "C" ShareErrorCode hbmpc_dev_apply_rows_lists_in_kernel(hbmpc_ctx* ctx, s
     const size_t size = domain_size(n), dp1 = d + 1;
     if (is_gold(ctx)) {  // k_eval_fft1_mix: the n x n mixing step on domains of up to 16 points, any batch size
         *yes_out = ctx->list_rows_in_kernel && !ctx->force_generic && dp1 == n && size <= 16 && n >= 3;
+        return ShareSuccess;
+    }
+    if (ctx->impl == IMPL_U29 && ctx->list_rows_in_kernel && !ctx->force_generic && dp1 == n && size <= 8 && n >= 3) {  // the same kernel over Fr, 3 .. 8 parties
+        *yes_out = 1;
         return ShareSuccess;
     }
     *yes_out = ctx->impl == IMPL_U29 && ctx->matrix_cores && ctx->mfma_bfly && !ctx->force_generic && ctx->list_rows_in_kernel && dp1 >= 2 &&

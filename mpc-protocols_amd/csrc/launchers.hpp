@@ -132,6 +132,7 @@ void launch_check_top_coeff(int ew64, const uint64_t* top, const uint8_t* status
 void launch_check_double(int ew64, const uint64_t* ct, const uint64_t* c2t, size_t G, int m, int t, uint32_t* bad, hipStream_t s);
 void launch_check_double_c0(int ew64, const uint64_t* c0t, const uint32_t* degt, const uint64_t* c02t, const uint32_t* deg2t, size_t G, int t,
                             uint32_t* bad, hipStream_t s, size_t columns = 0);
+bool launch_fft1_mix_lo(int log, int cnt, const uint32_t* x, size_t xs, size_t G, int n, const uint32_t* tw, const MixOut& o, hipStream_t s);
 bool launch_gold_fft1_mix(int log, int cnt, const uint32_t* x, size_t xs, size_t G, int n, const uint32_t* tw, const MixOut& o, hipStream_t s);
 void launch_rows_party_major(int ew64, const uint64_t* src, size_t G, size_t K, int row0, int rows, int nother, uint64_t* dst, hipStream_t s);
 void launch_take_c0(int ew64, const uint64_t* coeffs, size_t G, int m, uint64_t* c0, hipStream_t s);
