@@ -236,6 +236,19 @@ impl GpuShares {
         self.check(rc, 0)?;
         Ok(s)
     }
+    /// A host that hands the library buffers from `hipMallocAsync`: the release threshold of the device's stream-ordered pool (0, the
+    /// platform default, is the configuration under which such buffers are NOT safe: include/hbmpc_hip.h, "Device buffers") ...
+    pub fn stream_pool_release_threshold(&self) -> Result<u64, InterpolateError> {
+        let mut thr = 0u64;
+        let rc = unsafe { sys::hbmpc_stream_pool_release_threshold(self.ctx, &mut thr) };
+        self.check(rc, 0)?;
+        Ok(thr)
+    }
+    /// ... and the one-call remedy: the pool keeps its freed blocks from here on
+    pub fn stream_pool_retain(&self) -> Result<(), InterpolateError> {
+        let rc = unsafe { sys::hbmpc_stream_pool_retain(self.ctx) };
+        self.check(rc, 0)
+    }
     fn wrap(&self, rc: sys::ShareErrorCode, pipe: *mut sys::HbmpcPipe, n: usize) -> Result<GpuPipeline<'_>, InterpolateError> {
         self.check(rc, n)?;
         Ok(GpuPipeline { gpu: self, pipe, owned: true })
