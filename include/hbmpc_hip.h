@@ -602,7 +602,7 @@ ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows(hbmpc_ctx* ctx, const uint64_
  * for the slice s whose [k0, k0 + count) holds k (at most two slices, ascending and disjoint: a consumer that wants the first
  * N of a party's list in one array and the next N in another -- TripleGen's a and b -- names both; batch elements no slice
  * holds are not written).  The other rows go to y_out[row][G] as above; the list rows of y_out are unspecified.  Large Fr batches
- * on domains of 8 and 16 points write the lists from the kernel that computes them; every other shape (and
+ * on domains of 8 and 16 points (and the shapes of the lane kernel named below) write the lists from the kernel that computes them; every other shape (and
  * hbmpc_set_producer_fusion(ctx, 0)) computes all of y_out and copies the slices out with hbmpc_dev_transpose -- same bytes. */
 typedef struct {
     void* dst_dev;
@@ -623,8 +623,10 @@ ShareErrorCode hbmpc_gl_dev_vandermonde_apply_rows_lists(hbmpc_ctx* ctx, const u
  * call over (verifier, k) chunks with sender rows (n - list_rows) K apart instead of one call per verifier -- at the reference's own
  * batch sizes (K of 7 000 .. 15 000 columns, n = 16) thirty launches of 10 - 13 us each become three (profiles/r04_protocol_batch_sizes.txt).
  * others_out_dev holds parties * (n - list_rows) * K elements (below 4 GiB); y_out_dev (n * G elements) is workspace here: its contents
- * are unspecified.  Shapes the list kernel covers (hbmpc_dev_apply_rows_lists_in_kernel says which: Fr, 5 .. 16 rows, large batches) write
- * both kinds of rows from the kernel that computes them; every other shape computes y_out and copies -- same bytes either way. */
+ * are unspecified.  Shapes a list kernel covers (hbmpc_dev_apply_rows_lists_in_kernel says which, for d = n - 1: Fr with 5 .. 16 parties at
+ * large batches on the matrix cores, Fr with 3 .. 8 parties and Goldilocks with 3 .. 16 at any batch size on the single-pass lane kernel,
+ * csrc/kernels_eval.hpp: k_eval_fft1_mix) write both kinds of rows from the kernel that computes them, in one launch; every other shape
+ * computes y_out and copies -- same bytes either way. */
 ShareErrorCode hbmpc_dev_vandermonde_apply_rows_split(hbmpc_ctx* ctx, const U256* x_rows_dev, size_t x_row_stride, size_t G, size_t n, size_t d,
                                                       U256* tmp_dev, U256* y_out_dev, size_t list_row0, size_t list_rows, size_t K,
                                                       const hbmpc_list_slice* slices, size_t n_slices, U256* others_out_dev, void* stream);
