@@ -245,21 +245,18 @@ struct Producer : hbmpc_pipe {
     Producer(hbmpc_ctx* cx, size_t n_, size_t t_, size_t K_, void* s) : hbmpc_pipe(cx, s), n(n_), t(t_), K(K_) {}
     void deal_one(const unsigned char* coeffs, size_t deg, unsigned char* S) {
         // compute_shares of every dealer's K polynomials: coeffs [dealer][K][deg + 1] -> S [dealer][recipient][K] is the party-batched
-        // encode's layout.  A launch per dealer is at the memory rate only from some 10^6 polynomials; below that the dealers go
-        // together: up to 2 048 chunks per call through the wave-per-chunk kernels, a mid-size batch in ONE launch over (dealer, polynomial)
-        // (hbmpc_dev_vandermonde_apply_parties: the point-pair matrix-core kernel on domains of 8 / 16 points, the lane kernels elsewhere) -- at the reference's own batch sizes (K ~ 7 000 .. 15 000, n = 16) 16 launches of 10 us each
-        // were 45 % of the producers' time (profiles/r04_protocol_batch_sizes.txt)
+        // encode's layout (hbmpc_dev_vandermonde_apply_parties).  A launch per dealer is at the memory rate only from some 10^6 polynomials;
+        // below that all dealers go into ONE launch over (dealer, polynomial), whatever kernel family the size takes: the wave-per-chunk
+        // kernels up to 2 048 chunks, the point-pair matrix-core kernel on domains of 8 / 16 points from 16 384, the lane kernels elsewhere.
+        // At the node's batch sizes (K ~ 7 000 .. 15 000, n = 16) 16 launches of 10 us each were 45 % of the producers' time
+        // (profiles/r04_protocol_batch_sizes.txt); at small ones (n = 16, 367 polynomials per dealer) one launch takes 12.6 us against
+        // 23.7 for slices that stay within the wave-per-chunk kernels' range, at 1 024 polynomials 13.2 against 48.7.
         auto together = [&](size_t p, size_t cnt) {
             const unsigned char* co = coeffs + p * K * (deg + 1) * f.eb;
             unsigned char* out = S + p * n * K * f.eb;
             PL(f.gl ? hbmpc_gl_dev_vandermonde_apply_parties(ctx, (const uint64_t*)co, K, n, deg, cnt, (uint64_t*)out, stream)
                     : hbmpc_dev_vandermonde_apply_parties(ctx, (const U256*)co, K, n, deg, cnt, (U256*)out, stream));
         };
-        if (K <= 1024) {  // as many dealers per call as the wave-per-chunk kernels take in one launch (2048 chunks over all of them)
-            const size_t per = 2048 / K;
-            for (size_t p = 0; p < n; p += per) together(p, n - p < per ? n - p : per);
-            return;
-        }
         if (K <= dealers_together_max) {  // as many dealers per call as the one-launch form's 32-bit offsets allow (4 GiB of outputs, of inputs)
             const size_t lim = ((size_t)1 << 32) - 1;
             const size_t per = std::min(n, std::min(lim / (n * K * f.eb), lim / (K * (deg + 1) * f.eb)));
