@@ -281,10 +281,10 @@ struct Producer : hbmpc_pipe {
     // Mid-size batches (the reference's own: some thousands of columns per dealer): one verifier's decode is a launch of ~10 us that
     // does not fill the chip, and there are 2t (RanSha) or 2 (n - t - 1) (RanDouSha) of them.  Where the mixing kernel can write the
     // verifiers' rows party-major, all verifiers of a kind are ONE decode over (verifier, column) chunks (profiles/r04_protocol_batch_sizes.txt).
-    // Measured ahead of a call per verifier up to 250 000 columns (n = 16: RanSha 0.742 -> 0.616 ms at 80 000, RanDouSha 4.39 -> 3.92 at 250 000), even
-    // at 699 050 (config 4's producers); from 2^19 columns on -- and where the party-major block would pass 4 GiB -- a call each, without the extra rows.
-    // Shapes the list kernel does not cover (Goldilocks, 4-point domains) pay one more pass for the party-major rows (k_rows_party_major):
-    // from three verifiers on that is still fewer launches.
+    // Measured ahead of a call per verifier up to 250 000 columns (n = 16: RanSha 0.742 -> 0.616 ms at 80 000, RanDouSha 4.39 -> 3.92 at 250 000), level
+    // with it at 699 050 (config 4's producers); from 2^19 columns on -- and where the party-major block would pass 4 GiB -- a call each, without the
+    // extra rows.  Shapes no list kernel covers (more than 16 parties; 9 .. 16 over Fr at small batches) pay one more pass for the party-major rows
+    // (k_rows_party_major): from three verifiers on that is still fewer launches.
     bool verifiers_together(size_t nver) const {
         int yes = 0;
         if (nver < 2 || K >= ((size_t)1 << 19) || n * nver * K * f.eb >= ((size_t)1 << 32)) return false;
